@@ -1,0 +1,176 @@
+/*
+ * ammsb.h -- C ABI of the MI355X-native SG-MCMC a-MMSB hot path (libammsb_hip.so).
+ *
+ * Drop-in boundary for the per-iteration device work of ielhelw/mcmc-ammsb-gpu: each entry
+ * point replaces one reference operator (a C++ functor that JIT-builds an OpenCL/CUDA program and
+ * launches it through CLCudaAPI).  The reference has no FFI layer of its own; what a binding would
+ * attach to is the functor API in mcmc/{phi,beta,perplexity,sample,random,cuckoo}.h, cited per
+ * function below (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative AMMSB_E* code; nothing aborts, nothing
+ *     throws.  ammsb_strerror() names a code; ammsb_last_error(ctx) adds detail.
+ *   - device pointers are raw HBM addresses (hipMalloc / torch tensor data_ptr()); `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work: no hidden
+ *     synchronisation, no allocation after ammsb_ctx_create() (safe inside hipGraph capture).
+ *   - plain C types only; structs are POD, passed by pointer, copied before return.
+ *   - "wg" arguments are the reference's work-group sizes (Config::phi_wg_size, beta_wg_size,
+ *     ppx_wg_size, neighbor_sampler_wg_size).  They fix the RNG-stream <-> (group, lane) mapping and
+ *     the WG_SUM summation order exactly as in the reference kernels; the physical launch shape is
+ *     the library's own business.  Hot kernels need a power of two in [1, 1024].
+ */
+#ifndef AMMSB_H
+#define AMMSB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMMSB_VERSION 100
+
+enum {
+  AMMSB_OK = 0,
+  AMMSB_EINVAL = -1,   /* bad argument (null pointer, wg not a power of two, K/wg too large, ...) */
+  AMMSB_EHIP = -2,     /* a HIP runtime call failed; see ammsb_last_error() */
+  AMMSB_ENOMEM = -3,   /* workspace allocation failed */
+  AMMSB_ENODEV = -4,   /* no usable gfx950 device */
+  AMMSB_ERANGE = -5    /* size exceeds what the launch shape supports */
+};
+
+#define AMMSB_MAX_GROUPS 65535u /* mcmc/types.cc:537 GetMaxGroups() */
+#define AMMSB_RPM_MAX_BLOCKS 32 /* mcmc/partitioned-alloc.h:15 */
+
+/* one xorshift128+ stream; mcmc/random.h:17-18 random_seed_t (ulong2) */
+typedef struct { uint64_t x, y; } ammsb_seed;
+
+/* kernel constants the reference bakes in with -D flags, mcmc/config.cc:66-83 */
+typedef struct {
+  uint64_t N, K, E;
+  uint32_t num_node_sample; /* NUM_NEIGHBORS */
+  float alpha, a, b, c, epsilon, eta0, eta1;
+} ammsb_params;
+
+/* device view of RowPartitionedMatrix<float>, mcmc/partitioned-alloc.h:14-29 (64-bit offsets) */
+typedef struct {
+  void* blocks[AMMSB_RPM_MAX_BLOCKS];
+  uint64_t rows_in_block;
+  uint64_t num_rows, num_cols;
+  uint32_t num_blocks;
+} ammsb_rpm;
+
+/* device view of the cuckoo edge set, mcmc/cuckoo.cc:17-21; slots = image of Set::Serialize()
+ * (cuckoo.cc:211-220): [2 buckets][num_bins][4 slots] u64, empty = UINT64_MAX */
+typedef struct {
+  const uint64_t* slots;
+  uint64_t num_bins;
+  uint32_t prime_idx;
+} ammsb_set;
+
+/* result of one perplexity pass, device resident; mcmc/perplexity.h:60-63 */
+typedef struct {
+  double link_ll, nonlink_ll;       /* sums of log(ppx_e) */
+  uint64_t link_cnt, nonlink_cnt;
+} ammsb_ppx_sums;
+
+typedef struct ammsb_ctx ammsb_ctx;
+
+/* flags for ammsb_update_phi / ammsb_update_theta */
+#define AMMSB_NOISE_OFF 1u /* Config::phi_disable_noise: PHI_RANDN(X) := 1, phi.cc:673-677 */
+
+int ammsb_version(void);
+const char* ammsb_strerror(int code);
+const char* ammsb_last_error(const ammsb_ctx* ctx);
+
+/* Apply the "%e" round trip floats take through MakeCompileFlags (config.cc:57-83). */
+int ammsb_params_quantize(ammsb_params* p);
+/* get_eps_t, learner.cc:41-43 (evaluated on the host and passed to kernels by value) */
+float ammsb_eps_t(const ammsb_params* p, uint32_t step_count);
+
+/* One context per device.  Allocates the (small) reduction workspace.  Replaces the per-operator
+ * Program/Kernel construction in PhiUpdater / BetaUpdater / PerplexityCalculator ctors. */
+int ammsb_ctx_create(int device_id, const ammsb_params* params, ammsb_ctx** out);
+int ammsb_ctx_destroy(ammsb_ctx* ctx);
+int ammsb_ctx_params(const ammsb_ctx* ctx, ammsb_params* out);
+
+/* RandomInit, random.cc:31-43: seeds[i] = {sx + i, sy + i}.  Replaces OpenClRandomFactory::CreateRandom. */
+int ammsb_rng_init(ammsb_ctx* ctx, ammsb_seed* seeds, uint64_t n, uint64_t sx, uint64_t sy, void* stream);
+
+/* Set_HasEdge over a key list (the `find` kernel of cuckoo-test.cc:45-53). out[i] = 0/1. */
+int ammsb_set_has(ammsb_ctx* ctx, const ammsb_set* set, const uint64_t* keys, uint64_t n, uint8_t* out,
+                  void* stream);
+
+/* random::RandomGammaAndNormalize, random.cc:159-167: pi rows ~ Gamma(eta0, eta1) from N*32 streams
+ * (caller initialises them with {11,113}), then row-normalise; phi_sum[row] = row sum. */
+int ammsb_pi_init_gamma(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, float eta0, float eta1,
+                        ammsb_seed* seeds, void* stream);
+
+/* NeighborSampler::operator(), sample.cc:111-121 + kernel :48-77.  table: [n_nodes, 2n] scratch
+ * (GetHash()), packed: [n_nodes, n] (GetData()).  seeds: >= min(ceil(n_nodes/wg), 65535/wg)*wg streams. */
+int ammsb_sample_neighbors(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes,
+                           uint32_t wg, uint32_t* table, uint32_t* packed, void* stream);
+
+/* PhiUpdater::operator() first half, phi.cc:728-757, kernel update_phi (work-group variants
+ * phi.cc:214-302).  Virtual group g (of G = min(n_nodes, 65535)) handles nodes g, g+G, ...; lane l of
+ * group g owns stream seeds[g*wg + l].  Only groups in [group_begin, group_end) are processed (the
+ * multi-GPU shard; pass 0, UINT32_MAX for all).  phi_vec: [n_nodes, K], row i for nodes[i]. */
+int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
+                     const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
+                     uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
+                     uint32_t group_begin, uint32_t group_end, float* phi_vec, void* stream);
+
+/* PhiUpdater::operator() second half, phi.cc:758-762, kernel update_pi (phi.cc:177-197):
+ * pi[nodes[i], :] = phi_vec[i, :] / sum, phi_sum[nodes[i]] = sum (WG_SUM order for `wg`). */
+int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
+                    const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, void* stream);
+
+/* BetaUpdater::operator() gradient half, beta.cc:334-366: sum_theta + calculate_grads_partial +
+ * sum_grads over edges [edge_begin, edge_end) of the mini-batch.  grads_out: [2K] = the sum over
+ * those edges (the mathematical sum; the reference's serial partial-row order is not reproduced, and
+ * its stale-row read for > 65535 edges, beta.cc:354-361, is not replicated). */
+int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                     const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
+                     uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream);
+
+/* BetaUpdater::operator() update half, beta.cc:368-383: update_theta (SGLD, stream k for component k,
+ * r0 then r1) followed by beta = pair-normalised theta.  seeds: [K]. */
+int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, uint32_t step_count,
+                       float scale, ammsb_seed* seeds, uint32_t flags, void* stream);
+
+/* beta = pair-normalised theta only (random.h:70-79 RandomAndNormalize's device half). */
+int ammsb_beta_from_theta(ammsb_ctx* ctx, const float* theta, float* beta, void* stream);
+
+/* PerplexityCalculator::operator(), perplexity.cc:251-274, kernel :159-181 + the four reductions
+ * (:318-331).  Edges [edge_begin, edge_end) of the held-out list; ppx_per_edge is the running-mean
+ * state (indexed by global edge position); call_count is 1-based.  out: device ammsb_ppx_sums. */
+int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const ammsb_set* heldout_set,
+                     const uint64_t* edges, uint32_t n_edges, uint32_t edge_begin, uint32_t edge_end,
+                     uint32_t call_count, uint32_t wg, float* ppx_per_edge, ammsb_ppx_sums* out, void* stream);
+
+/* ---- wg_* primitives (test entry points; kernels of algorithm/{sum,normalize,sort}.cc) ---- */
+/* WG_SUM_KERNEL_TT, sum.cc:44-52: out[r] = WG_SUM(in + r*len, len) with `wg` lanes (any wg in [1,1024]) */
+int ammsb_wg_sum_f32(ammsb_ctx* ctx, const float* in, float* out, uint32_t rows, uint32_t len, uint32_t wg,
+                     void* stream);
+int ammsb_wg_sum_u32(ammsb_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t rows, uint32_t len,
+                     uint32_t wg, void* stream);
+/* WG_NORMALIZE_KERNEL_TT, normalize.cc:25-32 (Normalizer<T>, normalize.h:16-55); sums optional */
+int ammsb_wg_normalize_f32(ammsb_ctx* ctx, float* inout, float* sums, uint32_t rows, uint32_t len, uint32_t wg,
+                           void* stream);
+/* WG_SUM_PARTITIONED_KERNEL / WG_NORMALIZE_PARTITIONED_KERNEL, sum.cc:54-65, normalize.cc:34-52 */
+int ammsb_rpm_sum_f32(ammsb_ctx* ctx, const ammsb_rpm* m, float* out, uint32_t wg, void* stream);
+int ammsb_rpm_normalize_f32(ammsb_ctx* ctx, const ammsb_rpm* m, float* sums, uint32_t wg, void* stream);
+/* WG_SORT_TT, sort.cc:11-32: one group sorts len = wg elements (power of two <= 1024) */
+int ammsb_wg_sort_u32(ammsb_ctx* ctx, const uint32_t* in, uint32_t* out, uint32_t len, void* stream);
+int ammsb_wg_sort_f32(ammsb_ctx* ctx, const float* in, float* out, uint32_t len, void* stream);
+/* the `generate` kernel of random-test.cc:33-45: thread t writes `per_stream` normals from stream t */
+int ammsb_randn_fill(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_streams, uint32_t per_stream, float* out,
+                     void* stream);
+/* the `fetch` kernel of test-partitioned-alloc.cc:53-62: out[0..1] = row[col], row[col+1] (as u32 bits) */
+int ammsb_rpm_fetch(ammsb_ctx* ctx, const ammsb_rpm* m, uint64_t row, uint64_t col, uint32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMMSB_H */

@@ -1,0 +1,320 @@
+// beta / theta pipeline for gfx950.
+//
+// Replaces BetaUpdater::operator() (mcmc/beta.cc:334-384): sum_theta (:30-37),
+// calculate_grads_partial work-group variant (:174-233), sum_grads (:39-49), update_theta (:51-82)
+// and the theta->beta copy + pair normalisation (:376-383, normalize.cc:13-32).
+//
+// The reference gives every edge its own work-group, keeps a 2K-float accumulator per group in LDS,
+// spills one partial row per group to HBM (as many bytes as the pi rows it read) and then sums the
+// rows with 2K serial threads.  Here a virtual group keeps the 2K accumulators of the columns its
+// lanes own in registers across all the edges it walks, so only P <= 2048 partial rows leave the
+// chip; a second small kernel reduces them in a fixed order.  The per-edge arithmetic (two WG_SUMs,
+// probs, gradient terms) is the reference's, lane for lane; the order in which edges are added is
+// not (see include/ammsb.h, ammsb_beta_grads).
+#pragma clang fp contract(off)
+
+#include "ammsb_ctx.h"
+#include "ammsb_dev.h"
+
+using namespace ammsb;
+
+namespace {
+
+struct BetaArgs {
+  const float* theta;
+  const float* beta;
+  ammsb_rpm pi;
+  ammsb_set set;
+  const uint64_t* edges;
+  float* partials;   // [P, 2K]
+  float* theta_sum;  // [K]
+  uint32_t edge_begin, edge_end, P, K;
+  float epsilon;
+};
+
+template <int L, int KPT>
+__global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaArgs a) {
+  using Grp = Group<L>;
+  __shared__ float aux[Grp::AUX];
+  const int l = Grp::lane();
+  const uint32_t gs = blockIdx.x * Grp::PER_BLOCK + Grp::slot();  // partial-row slot
+  const bool live = gs < a.P;
+  const uint32_t K = a.K;
+  const float EPS = a.epsilon;
+
+  // per-lane constants for the columns this lane owns
+  float bk[KPT], omb[KPT], d0n[KPT], d1l[KPT], noo[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t k = l + j * L;
+    if (k < K) {
+      const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
+      const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
+      if (gs == 0) a.theta_sum[k] = ts;
+      const float oo = 1.0f / ts;
+      bk[j] = a.beta[2 * k + 1];
+      omb[j] = 1.0f - bk[j];
+      d0n[j] = 1.0f / t0 - oo;  // y = 0: (1 - y) / Theta0 - 1/theta_sum
+      d1l[j] = 1.0f / t1 - oo;  // y = 1:  y / Theta1      - 1/theta_sum
+      noo[j] = 0.0f - oo;       // the other component: 0 / Theta - 1/theta_sum
+    } else {
+      bk[j] = omb[j] = d0n[j] = d1l[j] = noo[j] = 0.0f;
+    }
+  }
+
+  float acc0[KPT], acc1[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) acc0[j] = acc1[j] = 0.0f;
+
+  const uint32_t n_edges = a.edge_end - a.edge_begin;
+  const uint32_t trips = (n_edges + a.P - 1) / a.P;  // uniform
+  int phase = 0;
+
+  // software pipeline: the two rows of edge t+1 are requested before edge t is consumed
+  float pa[2][KPT], pb[2][KPT];
+  uint64_t key[2] = {0, 0};
+  bool have[2] = {false, false};
+  auto fetch = [&](int b, uint32_t t) {
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
+    have[b] = live && t < trips && e < a.edge_end;
+    uint32_t u = 0, v = 0;
+    if (have[b]) {
+      const uint64_t edge = a.edges[e];
+      u = (uint32_t)(edge >> 32);
+      v = (uint32_t)(edge & 0xffffffffu);
+      key[b] = make_edge(u, v);
+    }
+    const float* ra = rpm_row(a.pi, u);
+    const float* rb = rpm_row(a.pi, v);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      const bool ok = have[b] && k < K;
+      pa[b][j] = ok ? ra[k] : 0.0f;
+      pb[b][j] = ok ? rb[k] : 0.0f;
+    }
+  };
+  auto consume = [&](int b) {
+    const bool y = have[b] && set_has(a.set, key[b]);
+    float scratch = 0.0f, ppart = 0.0f;
+    float probs[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {  // CALC_PROBS, beta.cc:145-160
+      const float f = pa[b][j] * pb[b][j];
+      scratch += f;
+      probs[j] = y ? bk[j] * f : omb[j] * f;
+      ppart += probs[j];
+    }
+    const float pi_sum = Grp::sum(scratch, aux, phase);  // beta.cc:209-213
+    float probs_sum = Grp::sum(ppart, aux, phase);       // beta.cc:214-217
+    const float w = y ? EPS : (1.0f - EPS);
+    const float prob_0 = w * (1.0f - pi_sum);
+    probs_sum += prob_0;
+    if (have[b]) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {  // CALC_GRADS, beta.cc:161-171
+        const float f = probs[j] / probs_sum;
+        acc0[j] += f * (y ? noo[j] : d0n[j]);
+        acc1[j] += f * (y ? d1l[j] : noo[j]);
+      }
+    }
+  };
+
+  fetch(0, 0);
+  for (uint32_t t = 0; t < trips; t += 2) {
+    fetch(1, t + 1);
+    consume(0);
+    fetch(0, t + 2);
+    consume(1);
+  }
+
+  if (live) {
+    float* out = a.partials + (uint64_t)gs * 2 * K;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      if (k < K) *reinterpret_cast<float2*>(out + 2 * k) = make_float2(acc0[j], acc1[j]);
+    }
+  }
+}
+
+// sum_grads: grads[c] = sum over the P partial rows, fixed order.  64 columns x 4 row-lanes per
+// block; row-lane r adds rows r, r+4, ... in ascending order, then the four are added 0+1+2+3.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, uint32_t P, uint32_t cols,
+                                                            float* out) {
+  __shared__ float red[4][64];
+  const uint32_t c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t r = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < cols)
+    for (uint32_t p = r; p < P; p += 4) s += partials[(uint64_t)p * cols + c];
+  red[r][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (r == 0 && c < cols) {
+    float t = red[0][threadIdx.x];
+    t += red[1][threadIdx.x];
+    t += red[2][threadIdx.x];
+    t += red[3][threadIdx.x];
+    out[c] = t;
+  }
+}
+
+// update_theta (beta.cc:51-82) + beta = pair-normalised theta (beta.cc:376-383; Normalizer slice 2,
+// wg 1: lsum = (0 + t0) + t1).  Thread k owns stream k: r0 for theta[k,0], then r1 for theta[k,1].
+__global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* beta, const float* grads,
+                                                           ammsb_seed* seeds, uint32_t K, float eps_t, float scale,
+                                                           float eta0, float eta1, uint32_t noise_on) {
+  __shared__ ZigTables zig;
+  zig_load(&zig);
+  __syncthreads();
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  ammsb_seed rs = seeds[k];
+  const float half = eps_t / 2.0f;
+  float th[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float r = noise_on ? rng_normal(rs, &zig) : 1.0f;
+    const float g = grads[2 * k + c];
+    const float t = theta[2 * k + c];
+    const float eta = c == 0 ? eta0 : eta1;
+    const float ep = eps_t * t;
+    const float f = sqrtf(ep);
+    const float sg = scale * g;
+    float in = eta - t;
+    in = in + sg;
+    const float drift = half * in;
+    const float aa = t + drift;
+    const float bb = f * r;
+    const float v = fabsf(aa + bb);
+    th[c] = v > 1e-24f ? v : 1e-24f;
+  }
+  seeds[k] = rs;
+  theta[2 * k] = th[0];
+  theta[2 * k + 1] = th[1];
+  float lsum = 0.0f;
+  lsum += th[0];
+  lsum += th[1];
+  beta[2 * k] = th[0] / lsum;
+  beta[2 * k + 1] = th[1] / lsum;
+}
+
+__global__ void beta_from_theta_kernel(const float* theta, float* beta, uint32_t K) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const float t0 = theta[2 * k], t1 = theta[2 * k + 1];
+  float lsum = 0.0f;
+  lsum += t0;
+  lsum += t1;
+  beta[2 * k] = t0 / lsum;
+  beta[2 * k + 1] = t1 / lsum;
+}
+
+template <int L, int KPT>
+int launch_grads(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
+  using Grp = Group<L>;
+  const uint32_t blocks = (a.P + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  beta_grads_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+inline int pick_kpt(uint64_t K, uint32_t L) {
+  const uint64_t need = (K + L - 1) / L;
+  for (int c : {1, 2, 4, 8, 16})
+    if ((uint64_t)c >= need) return c;
+  return 0;
+}
+
+}  // namespace
+
+#define AMMSB_DISPATCH_KPT16(kpt, ...)                                \
+  switch (kpt) {                                                      \
+    case 1: { constexpr int KPT_ = 1; __VA_ARGS__; } break;           \
+    case 2: { constexpr int KPT_ = 2; __VA_ARGS__; } break;           \
+    case 4: { constexpr int KPT_ = 4; __VA_ARGS__; } break;           \
+    case 8: { constexpr int KPT_ = 8; __VA_ARGS__; } break;           \
+    case 16: { constexpr int KPT_ = 16; __VA_ARGS__; } break;         \
+    default: return AMMSB_ERANGE;                                     \
+  }
+
+#define AMMSB_DISPATCH_HOT_L(wg, ...)                                 \
+  switch (wg) {                                                       \
+    case 16: { constexpr int L_ = 16; __VA_ARGS__; } break;           \
+    case 32: { constexpr int L_ = 32; __VA_ARGS__; } break;           \
+    case 64: { constexpr int L_ = 64; __VA_ARGS__; } break;           \
+    case 128: { constexpr int L_ = 128; __VA_ARGS__; } break;         \
+    case 256: { constexpr int L_ = 256; __VA_ARGS__; } break;         \
+    case 512: { constexpr int L_ = 512; __VA_ARGS__; } break;         \
+    case 1024: { constexpr int L_ = 1024; __VA_ARGS__; } break;       \
+    default: return AMMSB_EINVAL;                                     \
+  }
+
+extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                                const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
+                                uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && theta && beta && pi && training_set && edges && grads_out, "null argument");
+  AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
+                  "bad pi descriptor");
+  AMMSB_CHECK_ARG(ctx, pi->num_cols == ctx->params.K, "pi cols != K");
+  AMMSB_CHECK_ARG(ctx, training_set->slots && training_set->num_bins > 0 && training_set->prime_idx < 4,
+                  "bad set descriptor");
+  AMMSB_CHECK_ARG(ctx, is_pow2(wg) && wg >= 16 && wg <= 1024, "beta wg must be a power of two in [16, 1024]");
+  if (edge_end > n_edges) edge_end = n_edges;
+  hipStream_t s = as_stream(stream);
+  const uint32_t K = (uint32_t)ctx->params.K;
+  if (edge_begin >= edge_end) {  // an empty shard contributes zero
+    AMMSB_HIP(ctx, hipMemsetAsync(grads_out, 0, sizeof(float) * 2 * K, s));
+    return AMMSB_OK;
+  }
+  const int kpt = pick_kpt(K, wg);
+  if (kpt == 0) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_beta_grads: K=%u needs wg >= %u", K, (K + 15) / 16);
+    return AMMSB_ERANGE;
+  }
+  BetaArgs a;
+  a.theta = theta;
+  a.beta = beta;
+  a.pi = *pi;
+  a.set = *training_set;
+  a.edges = edges;
+  a.partials = ctx->grad_partials;
+  a.theta_sum = ctx->theta_sum;
+  a.edge_begin = edge_begin;
+  a.edge_end = edge_end;
+  a.K = K;
+  a.epsilon = ctx->params.epsilon;
+  const uint32_t span = edge_end - edge_begin;
+  // enough slots to fill the chip (~8 waves per CU), never more than there are edges
+  uint32_t want = (uint32_t)ctx->num_cus * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
+  if (want < 64) want = 64;
+  if (want > ctx->max_partials) want = ctx->max_partials;
+  a.P = span < want ? span : want;
+  AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT16(kpt, {
+                         int rc = launch_grads<L_, KPT_>(ctx, a, s);
+                         if (rc) return rc;
+                       }));
+  sum_partials_kernel<<<(2 * K + 63) / 64, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, uint32_t step_count,
+                                  float scale, ammsb_seed* seeds, uint32_t flags, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds, "null argument");
+  const ammsb_params& p = ctx->params;
+  const uint32_t K = (uint32_t)p.K;
+  update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K,
+                                                                     ammsb_eps_t(&p, step_count), scale, p.eta0,
+                                                                     p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+extern "C" int ammsb_beta_from_theta(ammsb_ctx* ctx, const float* theta, float* beta, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && theta && beta, "null argument");
+  const uint32_t K = (uint32_t)ctx->params.K;
+  beta_from_theta_kernel<<<(K + 255) / 256, 256, 0, as_stream(stream)>>>(theta, beta, K);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}

@@ -1,0 +1,221 @@
+// Device-side building blocks shared by the gfx950 kernels: RNG streams, cuckoo lookup,
+// row-partitioned-matrix addressing and the WG_SUM-ordered group reduction.
+//
+// Arithmetic contract (matches the CPU oracle): IEEE binary32, no FMA contraction (the TU is built
+// with -ffp-contract=off), correctly rounded divide/sqrt (hipcc default), operations in the order
+// the reference kernel text writes them; exp/log evaluated in binary64 and rounded once.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ammsb.h"
+
+namespace ammsb {
+
+// --------------------------------------------------------------------------------------- RNG
+// xorshift128+ / uniform / randint / ziggurat normal / Marsaglia-Tsang gamma with the exact state
+// update and draw order of mcmc/random.cl.inc:13-49, :229-273, :353-395.
+
+#include "zig_tables.inc"  // zig_ytab / zig_wtab / zig_ktab (tools/gen_ziggurat_tables.py)
+
+struct ZigTables {  // LDS copy, 1.5 KiB per block
+  float ytab[128];
+  float wtab[128];
+  uint32_t ktab[128];
+};
+
+__device__ __forceinline__ void zig_load(ZigTables* t) {
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+    t->ytab[i] = zig_ytab[i];
+    t->wtab[i] = zig_wtab[i];
+    t->ktab[i] = zig_ktab[i];
+  }
+}
+
+__device__ __forceinline__ uint64_t rng_next(ammsb_seed& s) {  // random.cl.inc:13-25
+  uint64_t s1 = s.x;
+  const uint64_t s0 = s.y;
+  s.x = s0;
+  s1 ^= s1 << 23;
+  s.y = s1 ^ s0 ^ (s1 >> 17) ^ (s0 >> 26);
+  return s.y + s0;
+}
+
+__device__ __forceinline__ float rng_uniform(ammsb_seed& s) {  // random.cl.inc:34-35
+  const float r = 1.0f * (float)rng_next(s);
+  return r / 18446744073709551616.0f;  // (float)ULONG_MAX == 2^64
+}
+
+__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float powf_cr(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// gsl_ran_gaussian_ziggurat(sigma = 1), random.cl.inc:229-273
+__device__ __forceinline__ float rng_normal(ammsb_seed& s, const ZigTables* t) {
+  const float PARAM_R = 3.44428647676f;
+  uint32_t i, j;
+  int sign;
+  float x, y;
+  for (;;) {
+    const uint64_t k = rng_next(s);
+    i = (uint32_t)(k & 0xFF);
+    j = (uint32_t)((k >> 8) & 0xFFFFFF);
+    sign = (i & 0x80) ? +1 : -1;
+    i &= 0x7f;
+    x = (float)j * t->wtab[i];
+    if (j < t->ktab[i]) break;
+    if (i < 127) {
+      const float y0 = t->ytab[i], y1 = t->ytab[i + 1];
+      const float U1 = rng_uniform(s);
+      const float d = y0 - y1;
+      const float m = d * U1;
+      y = y1 + m;
+    } else {
+      const float U1 = 1.0f - rng_uniform(s);
+      const float U2 = rng_uniform(s);
+      const float l = logf_cr(U1) / PARAM_R;
+      x = PARAM_R - l;
+      const float h = 0.5f * PARAM_R;
+      const float tt = x - h;
+      const float a = -PARAM_R * tt;
+      y = expf_cr(a) * U2;
+    }
+    const float hx = -0.5f * x;
+    const float xx = hx * x;
+    if (y < expf_cr(xx)) break;
+  }
+  const float ss = (float)sign * 1.0f;
+  return ss * x;
+}
+
+__device__ __forceinline__ float rng_uniform_pos(ammsb_seed& s) {  // random.cl.inc:310-317
+  float x;
+  do {
+    x = rng_uniform(s);
+  } while (x == 0);
+  return x;
+}
+
+// gsl_ran_gamma, random.cl.inc:353-395 (non-recursive branch)
+__device__ __forceinline__ float rng_gamma(ammsb_seed& s, const ZigTables* t, float a, float b) {
+  float f = 1.0f;
+  while (a < 1) {
+    const float u = rng_uniform_pos(s);
+    const float ia = 1.0f / a;
+    f = f * powf_cr(u, ia);
+    a = 1.0f + a;
+  }
+  float x, v, u;
+  const float third = 1.0f / 3.0f;
+  const float d = a - third;
+  const float c = third / sqrtf(d);
+  for (;;) {
+    do {
+      x = rng_normal(s, t);
+      const float cx = c * x;
+      v = 1.0f + cx;
+    } while (v <= 0);
+    const float v2 = v * v;
+    v = v2 * v;
+    u = rng_uniform_pos(s);
+    float q = 0.0331f * x;
+    q = q * x;
+    q = q * x;
+    q = q * x;
+    if (u < 1.0f - q) break;
+    const float hx = 0.5f * x;
+    const float hxx = hx * x;
+    const float omv = 1.0f - v;
+    const float in = omv + logf_cr(v);
+    const float din = d * in;
+    if (logf_cr(u) < hxx + din) break;
+  }
+  float r = f * b;
+  r = r * d;
+  return r * v;
+}
+
+// ------------------------------------------------------------------------------------ cuckoo
+// Set_HasEdge, mcmc/cuckoo.cc:27-69.  Both 32-byte bins are fetched at once (two independent
+// 2 x 16 B loads each) instead of the reference's dependent second probe.
+
+__device__ const uint64_t kSetPrimes[8] = {15485807ull, 920429591ull, 379906717ull, 740320571ull,
+                                           256204747ull, 379927517ull, 13ull,        17ull};
+
+__device__ __forceinline__ uint64_t make_edge(uint32_t a, uint32_t b) {  // learner.cc:22-27
+  const uint32_t u = a < b ? a : b, v = a < b ? b : a;
+  return ((uint64_t)u << 32) | v;
+}
+
+__device__ __forceinline__ bool set_has(const ammsb_set& set, uint64_t k) {
+  const uint64_t h1 = (kSetPrimes[2 * set.prime_idx] * k) % set.num_bins;
+  const uint64_t h2 = (k ^ kSetPrimes[2 * set.prime_idx + 1]) % set.num_bins;
+  const ulonglong2* b1 = reinterpret_cast<const ulonglong2*>(set.slots + h1 * 4);
+  const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(set.slots + (set.num_bins + h2) * 4);
+  const ulonglong2 a0 = b1[0], a1 = b1[1], c0 = b2[0], c1 = b2[1];
+  return (a0.x == k) | (a0.y == k) | (a1.x == k) | (a1.y == k) | (c0.x == k) | (c0.y == k) |
+         (c1.x == k) | (c1.y == k);
+}
+
+// ------------------------------------------------------------------------- partitioned matrix
+// TTRowPartitionedMatrix_Row, mcmc/partitioned-alloc.h:22-29, with 64-bit offsets.
+
+__device__ __forceinline__ float* rpm_row(const ammsb_rpm& m, uint64_t row) {
+  if (m.num_blocks == 1) return reinterpret_cast<float*>(m.blocks[0]) + row * m.num_cols;
+  const uint64_t blk = row / m.rows_in_block;
+  const uint64_t off = (row % m.rows_in_block) * m.num_cols;
+  return reinterpret_cast<float*>(m.blocks[blk]) + off;
+}
+
+// -------------------------------------------------------------------------------- group sum
+// A "virtual group" is the reference's OpenCL work-group of L work-items (L a power of two).
+//   L <= 64: 64/L groups share one 64-thread block (one wave); reductions stay in registers.
+//   L  > 64: one group per block of L threads; partials cross waves through LDS.
+// group_sum() returns, in every lane of the group, exactly the value WG_SUM_TT_LOCAL_
+// (mcmc/algorithm/sum.cc:20-29) leaves in aux[0]: the halving tree aux[l] += aux[l+p2].  For the
+// in-wave part an XOR butterfly is used: since a+b == b+a bitwise, lane l and lane l^p2 compute the
+// same value at every step, so all lanes end with the tree's root.
+
+template <int L>
+struct Group {
+  static_assert(L >= 1 && L <= 1024 && (L & (L - 1)) == 0, "L must be a power of two <= 1024");
+  static constexpr int BLOCK = L < 64 ? 64 : L;
+  static constexpr int PER_BLOCK = BLOCK / L;
+  static constexpr int AUX = L > 64 ? 2 * L : 1;  // floats of LDS scratch (double buffered)
+
+  __device__ __forceinline__ static int lane() { return threadIdx.x & (L - 1); }
+  __device__ __forceinline__ static int slot() { return threadIdx.x / L; }
+
+  template <typename T>
+  __device__ __forceinline__ static T wave_tree(T v) {
+    constexpr int W = L < 64 ? L : 64;
+#pragma unroll
+    for (int p2 = W >> 1; p2 > 0; p2 >>= 1) v += __shfl_xor(v, p2, 64);
+    return v;
+  }
+
+  // `phase` alternates 0/1 between consecutive calls so that one barrier per call suffices.
+  template <typename T>
+  __device__ __forceinline__ static T sum(T v, T* aux, int& phase) {
+    if constexpr (L <= 64) {
+      return wave_tree(v);
+    } else {
+      T* a = aux + phase * L;
+      phase ^= 1;
+      const int lid = threadIdx.x;
+      a[lid] = v;
+      __syncthreads();
+#pragma unroll
+      for (int p2 = L >> 1; p2 >= 64; p2 >>= 1) {
+        if (lid < p2) a[lid] += a[lid + p2];
+        __syncthreads();
+      }
+      return wave_tree(a[lid & 63]);
+    }
+  }
+};
+
+inline __host__ __device__ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+}  // namespace ammsb

@@ -1,0 +1,323 @@
+// update_phi / update_pi for gfx950.
+//
+// Replaces PhiUpdater::operator() (mcmc/phi.cc:728-763) and the work-group kernels
+// update_phi / update_phi_for_nodeWG (phi.cc:214-302) and update_pi (phi.cc:177-197).
+//
+// Mapping.  The reference's OpenCL work-group of L = phi_wg_size work-items becomes a "virtual
+// group" (ammsb_dev.h Group<L>): lane l owns columns k = l, l+L, ... of the K-vector -- the same
+// ownership the reference uses, so each lane's WG_SUM partial, its RNG stream (seeds[g*L+l]) and
+// its draw order (ascending k) are the reference's.  Everything a lane owns lives in registers:
+// pi_a, grads, probs and DEPTH neighbour rows in flight (KPT = ceil(K/L) floats each).
+//
+// HBM traffic per mini-batch node: (n+1) pi rows read (random 4K-byte rows at K=1024) + one
+// phi_vec row written + n ids + <= 2n 32-byte cuckoo bins: 4K(n+2) + 68n + 8 bytes.  Rows are
+// streamed with lane-contiguous 256-byte wave loads; DEPTH rows per wave are kept in flight so that
+// ~12 waves/CU cover the HBM latency.  The n cuckoo probes of a node are issued by n lanes at once
+// (one latency instead of n dependent ones, as the reference's lane-0-style lookup would cost).
+#pragma clang fp contract(off)
+
+#include "ammsb_ctx.h"
+#include "ammsb_dev.h"
+
+using namespace ammsb;
+
+namespace {
+
+struct PhiArgs {
+  const float* beta;
+  ammsb_rpm pi;
+  const float* phi_sum;
+  ammsb_set set;
+  const uint32_t* nodes;
+  const uint32_t* neighbors;
+  ammsb_seed* seeds;
+  float* phi_vec;
+  uint32_t n_nodes, G, group_begin, group_end;
+  uint32_t K, n;
+  float eps_t, alpha, epsilon, Nn;
+  uint32_t noise_on;
+};
+
+template <int L, int KPT, int DEPTH>
+__global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiArgs a) {
+  using Grp = Group<L>;
+  extern __shared__ uint32_t s_nb_all[];  // [PER_BLOCK][n]: neighbour id | link bit << 31
+  __shared__ ZigTables zig;
+  __shared__ float aux[Grp::AUX];
+
+  const int l = Grp::lane();
+  const int slot = Grp::slot();
+  uint32_t* s_nb = s_nb_all + slot * a.n;
+  const uint32_t g = a.group_begin + blockIdx.x * Grp::PER_BLOCK + slot;
+  const bool live = g < a.group_end;
+  const uint32_t K = a.K, n = a.n;
+  const float EPS = a.epsilon;
+
+  if (a.noise_on) zig_load(&zig);
+
+  // per-lane constants: f = beta_k - EPSILON for a link, its exact negation for a non-link
+  float bf[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t k = l + j * L;
+    bf[j] = k < K ? a.beta[2 * k + 1] - EPS : 0.0f;
+  }
+
+  ammsb_seed rs = {0, 0};
+  if (live && a.noise_on) rs = a.seeds[(uint64_t)g * L + l];  // rand->base_[GET_GLOBAL_ID()], phi.cc:291
+
+  const uint32_t trips = (a.n_nodes + a.G - 1) / a.G;  // uniform over the block
+  int phase = 0;
+  for (uint32_t t = 0; t < trips; ++t) {
+    const uint64_t i = (uint64_t)g + (uint64_t)t * a.G;  // node index handled by this group
+    const bool on = live && i < a.n_nodes;
+    const uint32_t node = on ? a.nodes[i] : 0;
+
+    // ---- stage neighbour ids and the n link bits (one cuckoo probe per lane)
+    __syncthreads();
+    if (on)
+      for (uint32_t q = l; q < n; q += L) {
+        const uint32_t nb = a.neighbors[i * n + q];
+        const bool y = set_has(a.set, make_edge(node, nb));
+        s_nb[q] = nb | (y ? 0x80000000u : 0u);
+      }
+    __syncthreads();
+
+    const float phi_sum = on ? a.phi_sum[node] : 1.0f;
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = rpm_row(a.pi, node);
+    float pi_a[KPT], grads[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      pi_a[j] = (on && k < K) ? row_a[k] : 0.0f;
+      grads[j] = 0.0f;
+    }
+
+    float buf[DEPTH][KPT];
+    auto load_row = [&](float (&dst)[KPT], uint32_t q) {
+      uint32_t w = on ? (s_nb[q] & 0x7fffffffu) : 0u;  // idle groups never form an out-of-range row
+      if constexpr (L >= 64) w = __builtin_amdgcn_readfirstlane(w);  // uniform per wave: scalar row base
+      const float* row = rpm_row(a.pi, w);
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const uint32_t k = l + j * L;
+        dst[j] = (on && k < K) ? row[k] : 0.0f;
+      }
+    };
+    auto consume = [&](const float (&pin)[KPT], uint32_t q) {
+      const bool y = (s_nb[q] >> 31) != 0;
+      const float e = y ? EPS : 1.0f - EPS;
+      float probs[KPT];
+      float partial = 0.0f;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {  // phi.cc:241-253
+        const float f = y ? bf[j] : -bf[j];
+        float tt = pin[j] * f;
+        tt = tt + e;
+        probs[j] = pi_a[j] * tt;
+        partial += probs[j];
+      }
+      const float probs_sum = Grp::sum(partial, aux, phase);  // phi.cc:254-257
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {  // phi.cc:259-263
+        float qv = probs[j] / probs_sum;
+        const float den = pi_a[j] * phi_sum;
+        qv = qv / den;
+        grads[j] += qv - inv_phi_sum;
+      }
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+      if ((uint32_t)d < n) load_row(buf[d], d);
+    for (uint32_t q0 = 0; q0 < n; q0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const uint32_t q = q0 + d;
+        if (q < n) {
+          const uint32_t qn = q + DEPTH - 1;
+          if (qn < n) load_row(buf[(d + DEPTH - 1) % DEPTH], qn);
+          consume(buf[d], q);
+        }
+      }
+    }
+
+    // ---- SGLD step, phi.cc:265-274; lane l draws for k = l, l+L, ... in ascending order
+    if (on) {
+      float* out = a.phi_vec + i * K;
+      const float half = a.eps_t / 2;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const uint32_t k = l + j * L;
+        if (k < K) {
+          const float noise = a.noise_on ? rng_normal(rs, &zig) : 1.0f;
+          const float phi_k = pi_a[j] * phi_sum;
+          const float ng = a.Nn * grads[j];
+          float in = a.alpha - phi_k;
+          in = in + ng;
+          const float drift = half * in;
+          const float aa = phi_k + drift;
+          const float ep = a.eps_t * phi_k;
+          const float sq = sqrtf(ep);
+          const float bb = sq * noise;
+          const float v = fabsf(aa + bb);
+          out[k] = v > 1e-24f ? v : 1e-24f;
+        }
+      }
+    }
+  }
+  if (live && a.noise_on) a.seeds[(uint64_t)g * L + l] = rs;
+}
+
+// update_pi, phi.cc:177-197: copy phi_vec row into pi, WG_NORMALIZE it, phi_sum[node] = sum.
+template <int L, int KPT>
+__global__ __launch_bounds__(Group<L>::BLOCK) void update_pi_kernel(ammsb_rpm pi, float* phi_sum,
+                                                                     const float* phi_vec, const uint32_t* nodes,
+                                                                     uint32_t n_nodes, uint32_t K) {
+  using Grp = Group<L>;
+  __shared__ float aux[Grp::AUX];
+  const int l = Grp::lane();
+  const uint64_t i = (uint64_t)blockIdx.x * Grp::PER_BLOCK + Grp::slot();
+  const bool on = i < n_nodes;
+  const float* src = phi_vec + i * K;
+  float v[KPT];
+  float partial = 0.0f;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t k = l + j * L;
+    v[j] = (on && k < K) ? src[k] : 0.0f;
+    partial += v[j];
+  }
+  int phase = 0;
+  const float sum = Grp::sum(partial, aux, phase);
+  if (on) {
+    const uint32_t node = nodes[i];
+    float* row = rpm_row(pi, node);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      if (k < K) row[k] = v[j] / sum;
+    }
+    if (l == 0) phi_sum[node] = sum;
+  }
+}
+
+template <int L, int KPT>
+int launch_phi(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  using Grp = Group<L>;
+  constexpr int DEPTH = KPT >= 32 ? 2 : (KPT >= 16 ? 3 : 4);
+  const uint32_t blocks = (n_groups + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  const size_t lds = sizeof(uint32_t) * Grp::PER_BLOCK * a.n;
+  update_phi_kernel<L, KPT, DEPTH><<<blocks, Grp::BLOCK, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+template <int L, int KPT>
+int launch_pi(ammsb_ctx* ctx, const ammsb_rpm& pi, float* phi_sum, const float* phi_vec, const uint32_t* nodes,
+              uint32_t n_nodes, uint32_t K, hipStream_t s) {
+  using Grp = Group<L>;
+  const uint32_t blocks = (n_nodes + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  update_pi_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(pi, phi_sum, phi_vec, nodes, n_nodes, K);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+// smallest instantiated KPT >= ceil(K / L), or 0 if K is too long for this work-group size
+inline int pick_kpt(uint64_t K, uint32_t L) {
+  const uint64_t need = (K + L - 1) / L;
+  for (int c : {1, 2, 4, 8, 16, 32})
+    if ((uint64_t)c >= need) return c;
+  return 0;
+}
+
+}  // namespace
+
+#define AMMSB_DISPATCH_KPT(kpt, ...)                                  \
+  switch (kpt) {                                                      \
+    case 1: { constexpr int KPT_ = 1; __VA_ARGS__; } break;           \
+    case 2: { constexpr int KPT_ = 2; __VA_ARGS__; } break;           \
+    case 4: { constexpr int KPT_ = 4; __VA_ARGS__; } break;           \
+    case 8: { constexpr int KPT_ = 8; __VA_ARGS__; } break;           \
+    case 16: { constexpr int KPT_ = 16; __VA_ARGS__; } break;         \
+    case 32: { constexpr int KPT_ = 32; __VA_ARGS__; } break;         \
+    default: return AMMSB_ERANGE;                                     \
+  }
+
+#define AMMSB_DISPATCH_HOT_L(wg, ...)                                 \
+  switch (wg) {                                                       \
+    case 16: { constexpr int L_ = 16; __VA_ARGS__; } break;           \
+    case 32: { constexpr int L_ = 32; __VA_ARGS__; } break;           \
+    case 64: { constexpr int L_ = 64; __VA_ARGS__; } break;           \
+    case 128: { constexpr int L_ = 128; __VA_ARGS__; } break;         \
+    case 256: { constexpr int L_ = 256; __VA_ARGS__; } break;         \
+    case 512: { constexpr int L_ = 512; __VA_ARGS__; } break;         \
+    case 1024: { constexpr int L_ = 1024; __VA_ARGS__; } break;       \
+    default: return AMMSB_EINVAL;                                     \
+  }
+
+extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
+                                const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
+                                uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
+                                uint32_t group_begin, uint32_t group_end, float* phi_vec, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && beta && pi && phi_sum && training_set && nodes && neighbors && seeds && phi_vec,
+                  "null argument");
+  AMMSB_CHECK_ARG(ctx, n_nodes > 0, "mini-batch nodes size = 0");  // phi.cc:732
+  AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
+                  "bad pi descriptor");
+  AMMSB_CHECK_ARG(ctx, pi->num_cols == ctx->params.K && pi->num_rows == ctx->params.N, "pi shape != (N, K)");
+  AMMSB_CHECK_ARG(ctx, training_set->slots && training_set->num_bins > 0 && training_set->prime_idx < 4,
+                  "bad set descriptor");
+  AMMSB_CHECK_ARG(ctx, ctx->params.N < (1ull << 31), "N must be < 2^31");
+  AMMSB_CHECK_ARG(ctx, is_pow2(wg) && wg >= 16 && wg <= 1024, "phi wg must be a power of two in [16, 1024]");
+  const ammsb_params& p = ctx->params;
+  const int kpt = pick_kpt(p.K, wg);
+  if (kpt == 0) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_update_phi: K=%llu needs wg >= %llu", (unsigned long long)p.K,
+             (unsigned long long)((p.K + 31) / 32));
+    return AMMSB_ERANGE;
+  }
+  PhiArgs a;
+  a.beta = beta;
+  a.pi = *pi;
+  a.phi_sum = phi_sum;
+  a.set = *training_set;
+  a.nodes = nodes;
+  a.neighbors = neighbors;
+  a.seeds = seeds;
+  a.phi_vec = phi_vec;
+  a.n_nodes = n_nodes;
+  a.G = n_nodes < AMMSB_MAX_GROUPS ? n_nodes : AMMSB_MAX_GROUPS;  // phi.cc:745-747
+  a.group_begin = group_begin;
+  a.group_end = group_end < a.G ? group_end : a.G;
+  a.K = (uint32_t)p.K;
+  a.n = p.num_node_sample;
+  a.eps_t = ammsb_eps_t(&p, step_count);
+  a.alpha = p.alpha;
+  a.epsilon = p.epsilon;
+  a.Nn = (1.0f * (float)p.N) / (float)p.num_node_sample;  // phi.cc:265
+  a.noise_on = (flags & AMMSB_NOISE_OFF) ? 0u : 1u;
+  if (a.group_begin >= a.group_end) return AMMSB_OK;
+  const uint32_t n_groups = a.group_end - a.group_begin;
+  hipStream_t s = as_stream(stream);
+  AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, return (launch_phi<L_, KPT_>(ctx, a, n_groups, s))));
+  return AMMSB_OK;
+}
+
+extern "C" int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
+                               const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && pi && phi_sum && phi_vec && nodes, "null argument");
+  AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
+                  "bad pi descriptor");
+  AMMSB_CHECK_ARG(ctx, pi->num_cols == ctx->params.K, "pi cols != K");
+  AMMSB_CHECK_ARG(ctx, is_pow2(wg) && wg >= 16 && wg <= 1024, "phi wg must be a power of two in [16, 1024]");
+  if (n_nodes == 0) return AMMSB_OK;
+  const int kpt = pick_kpt(ctx->params.K, wg);
+  if (kpt == 0) return AMMSB_ERANGE;
+  const uint32_t K = (uint32_t)ctx->params.K;
+  hipStream_t s = as_stream(stream);
+  AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, return (launch_pi<L_, KPT_>(ctx, *pi, phi_sum, phi_vec, nodes,
+                                                                                n_nodes, K, s))));
+  return AMMSB_OK;
+}

@@ -1,0 +1,253 @@
+// Held-out perplexity for gfx950.
+//
+// Replaces PerplexityCalculatorBase::operator() (mcmc/perplexity.cc:251-274): the work-group kernel
+// calculate_ppx_partial_for_edge (:93-181) plus the four boost::compute / thrust reductions
+// (:318-331, perplexity.cu:27-37).  The reference stages the K products of every edge in a global
+// scratch buffer of H*K floats and re-reads them three times; here a lane keeps the products of the
+// columns it owns in registers, the WG_SUM order is unchanged, and the four per-edge output arrays
+// are folded into per-slot partial sums (binary64 for the log-likelihoods) reduced by a second
+// single-block kernel in a fixed order.
+#pragma clang fp contract(off)
+
+#include "ammsb_ctx.h"
+#include "ammsb_dev.h"
+
+using namespace ammsb;
+
+namespace {
+
+struct PpxArgs {
+  const float* beta;
+  ammsb_rpm pi;
+  ammsb_set set;
+  const uint64_t* edges;
+  float* ppx_per_edge;
+  double* ll_partials;               // [P, 2]
+  unsigned long long* cnt_partials;  // [P, 2]
+  uint32_t edge_begin, edge_end, P, K, call_count;
+  float epsilon;
+};
+
+template <int L, int KPT>
+__global__ __launch_bounds__(Group<L>::BLOCK) void ppx_kernel(const PpxArgs a) {
+  using Grp = Group<L>;
+  __shared__ float aux[Grp::AUX];
+  const int l = Grp::lane();
+  const uint32_t gs = blockIdx.x * Grp::PER_BLOCK + Grp::slot();
+  const bool live = gs < a.P;
+  const uint32_t K = a.K;
+
+  float bk[KPT], omb[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t k = l + j * L;
+    bk[j] = k < K ? a.beta[2 * k + 1] : 0.0f;
+    omb[j] = 1.0f - bk[j];
+  }
+
+  double ll_link = 0.0, ll_non = 0.0;
+  unsigned long long c_link = 0, c_non = 0;
+  const uint32_t n_edges = a.edge_end - a.edge_begin;
+  const uint32_t trips = (n_edges + a.P - 1) / a.P;
+  int phase = 0;
+  const float cm1 = (float)(a.call_count - 1), cc = (float)a.call_count;
+
+  float pa[2][KPT], pb[2][KPT];
+  uint64_t key[2] = {0, 0}, pos[2] = {0, 0};
+  bool have[2] = {false, false};
+  auto fetch = [&](int b, uint32_t t) {
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
+    have[b] = live && t < trips && e < a.edge_end;
+    uint32_t u = 0, v = 0;
+    if (have[b]) {
+      pos[b] = e;
+      key[b] = a.edges[e];  // used as stored: no canonicalisation (perplexity.cc:45-47)
+      u = (uint32_t)(key[b] >> 32);
+      v = (uint32_t)(key[b] & 0xffffffffu);
+    }
+    const float* ra = rpm_row(a.pi, u);
+    const float* rb = rpm_row(a.pi, v);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      const bool ok = have[b] && k < K;
+      pa[b][j] = ok ? ra[k] : 0.0f;
+      pb[b][j] = ok ? rb[k] : 0.0f;
+    }
+  };
+  auto consume = [&](int b) {
+    const bool y = have[b] && set_has(a.set, key[b]);
+    float s_part = 0.0f, f_part = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {  // perplexity.cc:100-119
+      const float f = pa[b][j] * pb[b][j];
+      f_part += f;
+      s_part += f * (y ? bk[j] : omb[j]);
+    }
+    const float fsum = Grp::sum(f_part, aux, phase);
+    float s = Grp::sum(s_part, aux, phase);
+    if (!y) {
+      const float t = 1.0f - fsum;
+      const float u1 = 1.0f - a.epsilon;
+      s += t * u1;
+    }
+    if (s < 1.0e-30f) s = 1.0e-30f;
+    if (have[b] && l == 0) {  // perplexity.cc:139-156
+      float ppx = a.ppx_per_edge[pos[b]];
+      float m = ppx * cm1;
+      m = m + s;
+      ppx = m / cc;
+      const float ll = logf_cr(ppx);
+      if (y) {
+        c_link += 1;
+        ll_link += (double)ll;
+      } else {
+        c_non += 1;
+        ll_non += (double)ll;
+      }
+      a.ppx_per_edge[pos[b]] = ppx;
+    }
+  };
+
+  fetch(0, 0);
+  for (uint32_t t = 0; t < trips; t += 2) {
+    fetch(1, t + 1);
+    consume(0);
+    fetch(0, t + 2);
+    consume(1);
+  }
+  if (live && l == 0) {
+    a.ll_partials[2 * gs] = ll_link;
+    a.ll_partials[2 * gs + 1] = ll_non;
+    a.cnt_partials[2 * gs] = c_link;
+    a.cnt_partials[2 * gs + 1] = c_non;
+  }
+}
+
+// fixed-order reduction of the P per-slot partials: thread t adds slots t, t+256, ... ascending,
+// then a halving tree over the 256 threads.
+__global__ __launch_bounds__(256) void ppx_reduce_kernel(const double* ll, const unsigned long long* cnt, uint32_t P,
+                                                          ammsb_ppx_sums* out) {
+  __shared__ double s_ll[2][256];
+  __shared__ unsigned long long s_c[2][256];
+  double a0 = 0, a1 = 0;
+  unsigned long long c0 = 0, c1 = 0;
+  for (uint32_t p = threadIdx.x; p < P; p += 256) {
+    a0 += ll[2 * p];
+    a1 += ll[2 * p + 1];
+    c0 += cnt[2 * p];
+    c1 += cnt[2 * p + 1];
+  }
+  s_ll[0][threadIdx.x] = a0;
+  s_ll[1][threadIdx.x] = a1;
+  s_c[0][threadIdx.x] = c0;
+  s_c[1][threadIdx.x] = c1;
+  __syncthreads();
+  for (int p2 = 128; p2 > 0; p2 >>= 1) {
+    if ((int)threadIdx.x < p2) {
+      s_ll[0][threadIdx.x] += s_ll[0][threadIdx.x + p2];
+      s_ll[1][threadIdx.x] += s_ll[1][threadIdx.x + p2];
+      s_c[0][threadIdx.x] += s_c[0][threadIdx.x + p2];
+      s_c[1][threadIdx.x] += s_c[1][threadIdx.x + p2];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out->link_ll = s_ll[0][0];
+    out->nonlink_ll = s_ll[1][0];
+    out->link_cnt = s_c[0][0];
+    out->nonlink_cnt = s_c[1][0];
+  }
+}
+
+template <int L, int KPT>
+int launch_ppx(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
+  using Grp = Group<L>;
+  const uint32_t blocks = (a.P + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  ppx_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+inline int pick_kpt(uint64_t K, uint32_t L) {
+  const uint64_t need = (K + L - 1) / L;
+  for (int c : {1, 2, 4, 8, 16, 32})
+    if ((uint64_t)c >= need) return c;
+  return 0;
+}
+
+}  // namespace
+
+#define AMMSB_DISPATCH_KPT(kpt, ...)                                  \
+  switch (kpt) {                                                      \
+    case 1: { constexpr int KPT_ = 1; __VA_ARGS__; } break;           \
+    case 2: { constexpr int KPT_ = 2; __VA_ARGS__; } break;           \
+    case 4: { constexpr int KPT_ = 4; __VA_ARGS__; } break;           \
+    case 8: { constexpr int KPT_ = 8; __VA_ARGS__; } break;           \
+    case 16: { constexpr int KPT_ = 16; __VA_ARGS__; } break;         \
+    case 32: { constexpr int KPT_ = 32; __VA_ARGS__; } break;         \
+    default: return AMMSB_ERANGE;                                     \
+  }
+
+#define AMMSB_DISPATCH_HOT_L(wg, ...)                                 \
+  switch (wg) {                                                       \
+    case 16: { constexpr int L_ = 16; __VA_ARGS__; } break;           \
+    case 32: { constexpr int L_ = 32; __VA_ARGS__; } break;           \
+    case 64: { constexpr int L_ = 64; __VA_ARGS__; } break;           \
+    case 128: { constexpr int L_ = 128; __VA_ARGS__; } break;         \
+    case 256: { constexpr int L_ = 256; __VA_ARGS__; } break;         \
+    case 512: { constexpr int L_ = 512; __VA_ARGS__; } break;         \
+    case 1024: { constexpr int L_ = 1024; __VA_ARGS__; } break;       \
+    default: return AMMSB_EINVAL;                                     \
+  }
+
+extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const ammsb_set* heldout_set,
+                                const uint64_t* edges, uint32_t n_edges, uint32_t edge_begin, uint32_t edge_end,
+                                uint32_t call_count, uint32_t wg, float* ppx_per_edge, ammsb_ppx_sums* out,
+                                void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && beta && pi && heldout_set && edges && ppx_per_edge && out, "null argument");
+  AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
+                  "bad pi descriptor");
+  AMMSB_CHECK_ARG(ctx, pi->num_cols == ctx->params.K, "pi cols != K");
+  AMMSB_CHECK_ARG(ctx, heldout_set->slots && heldout_set->num_bins > 0 && heldout_set->prime_idx < 4,
+                  "bad set descriptor");
+  AMMSB_CHECK_ARG(ctx, call_count >= 1, "call_count is 1-based");
+  AMMSB_CHECK_ARG(ctx, is_pow2(wg) && wg >= 16 && wg <= 1024, "ppx wg must be a power of two in [16, 1024]");
+  if (edge_end > n_edges) edge_end = n_edges;
+  hipStream_t s = as_stream(stream);
+  if (edge_begin >= edge_end) {
+    AMMSB_HIP(ctx, hipMemsetAsync(out, 0, sizeof(ammsb_ppx_sums), s));
+    return AMMSB_OK;
+  }
+  const uint32_t K = (uint32_t)ctx->params.K;
+  const int kpt = pick_kpt(K, wg);
+  if (kpt == 0) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_perplexity: K=%u needs wg >= %u", K, (K + 31) / 32);
+    return AMMSB_ERANGE;
+  }
+  PpxArgs a;
+  a.beta = beta;
+  a.pi = *pi;
+  a.set = *heldout_set;
+  a.edges = edges;
+  a.ppx_per_edge = ppx_per_edge;
+  a.ll_partials = ctx->ppx_partials;
+  a.cnt_partials = ctx->ppx_cnt_partials;
+  a.edge_begin = edge_begin;
+  a.edge_end = edge_end;
+  a.K = K;
+  a.call_count = call_count;
+  a.epsilon = ctx->params.epsilon;
+  const uint32_t span = edge_end - edge_begin;
+  uint32_t want = (uint32_t)ctx->num_cus * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
+  if (want < 64) want = 64;
+  if (want > ctx->max_ppx_blocks) want = ctx->max_ppx_blocks;
+  a.P = span < want ? span : want;
+  AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, {
+                         int rc = launch_ppx<L_, KPT_>(ctx, a, s);
+                         if (rc) return rc;
+                       }));
+  ppx_reduce_kernel<<<1, 256, 0, s>>>(a.ll_partials, a.cnt_partials, a.P, out);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}

@@ -1,0 +1,355 @@
+"""Host-side mirror of the reference's operator interface on top of the C ABI.
+
+Same names, argument meaning and error behaviour as the C++ functors of the reference, so that the
+parity tests read like the reference's own tests:
+
+    PhiUpdater            mcmc/phi.h:10-61      operator()(nodes, neighbors, n)
+    BetaUpdater           mcmc/beta.h:15-72     operator()(edges, n, scale), GetThetaSum(), GetGrads()
+    PerplexityCalculator  mcmc/perplexity.h:23-114   operator()()
+    NeighborSampler       mcmc/sample.h:16-49   operator()(n, nodes), GetData(), GetHash()
+    Random                mcmc/random.h:22-47   OpenClRandom (seed array)
+    DeviceSet             mcmc/cuckoo.h:69-86   OpenClSet
+    RowPartitionedMatrix  mcmc/partitioned-alloc.h:73-140
+
+torch is used for device memory and streams only.  Every method enqueues on the current torch HIP
+stream and returns without synchronising (the reference calls queue.Finish() after each launch; a
+caller that wants that behaviour calls torch.cuda.synchronize()).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import AmmsbError, NOISE_OFF, Params, PpxSums, Rpm, SetDesc, check
+
+SEED_DT = np.dtype([("x", np.uint64), ("y", np.uint64)])
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def make_params(N, K, E=0, num_node_sample=32, alpha=0.0, a=0.0315, b=1024.0, c=0.5, epsilon=1e-7,
+                eta0=1.0, eta1=1.0, quantize=True):
+    """mcmc::Config numeric fields (config.h:25-102) with main.cc's rule alpha == 0 -> 1/K
+    (main.cc:153).  quantize applies MakeCompileFlags' "%e" round trip (config.cc:57-83)."""
+    if alpha == 0:
+        alpha = float(np.float32(1.0) / np.float32(K))
+    p = Params(N, K, E, num_node_sample, alpha, a, b, c, epsilon, eta0, eta1)
+    if quantize:
+        check(_capi.load().ammsb_params_quantize(C.byref(p)))
+    return p
+
+
+class Context:
+    """One per device; owns the C-ABI context (replaces clcuda::Queue + the JIT-built programs)."""
+
+    def __init__(self, params, device=None):
+        if not torch.cuda.is_available():
+            raise AmmsbError("no HIP device visible: the MI355X path has no CPU fallback")
+        self.lib = _capi.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.params = params
+        self._ctx = C.c_void_p()
+        check(self.lib.ammsb_ctx_create(self.device.index, C.byref(params), C.byref(self._ctx)))
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def check(self, rc):
+        check(rc, self._ctx)
+
+    def close(self):
+        if self._ctx:
+            self.lib.ammsb_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- small allocation helpers (device memory comes from torch's caching allocator)
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def from_numpy(self, arr):
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        elif a.dtype == np.uint32:
+            a = a.view(np.int32)
+        elif a.dtype == SEED_DT:
+            a = a.view(np.int64).reshape(-1, 2)
+        return torch.from_numpy(a).to(self.device)
+
+
+def to_numpy(t, dtype=None):
+    a = t.detach().cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+class Random:
+    """OpenClRandom: `size` xorshift128+ streams, stream i seeded {sx+i, sy+i} (random.cc:31-43)."""
+
+    def __init__(self, ctx, size, seed):
+        self.ctx = ctx
+        self.size = int(size)
+        self.seeds = ctx.empty((self.size, 2), torch.int64)
+        self.SetSeed(seed)
+
+    def SetSeed(self, seed):
+        sx, sy = seed
+        self.ctx.check(self.ctx.lib.ammsb_rng_init(self.ctx.handle, _ptr(self.seeds), self.size,
+                                                   int(sx), int(sy), _stream()))
+
+    def GetSeeds(self):
+        return self.seeds
+
+    def host(self):
+        return to_numpy(self.seeds).view(np.uint64).reshape(-1, 2).copy().view(SEED_DT).reshape(-1)
+
+    def load(self, seeds):
+        self.seeds.copy_(self.ctx.from_numpy(seeds))
+
+
+class DeviceSet:
+    """OpenClSet: device image of a host cuckoo Set (cuckoo.cc:222-239).  `slots` is the array
+    Set::Serialize() returns; num_bins = BinsPerBucket(); prime_idx = PrimeIdx()."""
+
+    def __init__(self, ctx, slots, num_bins, prime_idx):
+        slots = np.ascontiguousarray(slots, dtype=np.uint64)
+        if slots.size != 2 * int(num_bins) * 4:
+            raise AmmsbError("set image has %d slots, expected 2*%d*4" % (slots.size, num_bins))
+        self.ctx = ctx
+        self.data = ctx.from_numpy(slots)
+        self.num_bins = int(num_bins)
+        self.prime_idx = int(prime_idx)
+        self.desc = SetDesc(self.data.data_ptr(), self.num_bins, self.prime_idx)
+
+    def Has(self, keys):
+        """The `find` kernel of cuckoo-test.cc:45-53 over a device or host key array."""
+        k = keys if torch.is_tensor(keys) else self.ctx.from_numpy(np.asarray(keys, dtype=np.uint64))
+        out = self.ctx.empty((k.numel(),), torch.uint8)
+        self.ctx.check(self.ctx.lib.ammsb_set_has(self.ctx.handle, C.byref(self.desc), _ptr(k), k.numel(),
+                                                  _ptr(out), _stream()))
+        return out
+
+
+class RowPartitionedMatrix:
+    """RowPartitionedMatrix<float> (partitioned-alloc.h:73-140): rows split into <= 32 blocks of
+    rows_in_block rows.  On a 288 GB MI355X one block holds any configuration of interest, so
+    rows_in_block defaults to all rows; a smaller value reproduces the reference's multi-block
+    layout (tests use 11+1 blocks)."""
+
+    def __init__(self, ctx, rows, cols, rows_in_block=0, dtype=torch.float32):
+        self.ctx = ctx
+        self.rows, self.cols = int(rows), int(cols)
+        self.rows_in_block = int(rows_in_block) if rows_in_block else self.rows
+        nfull, rem = divmod(self.rows, self.rows_in_block)
+        sizes = [self.rows_in_block] * nfull + ([rem] if rem else [])
+        if len(sizes) > _capi.RPM_MAX_BLOCKS:
+            raise AmmsbError("more than 32 blocks")
+        self.blocks = [ctx.empty((s, self.cols), dtype) for s in sizes]
+        self.desc = Rpm()
+        for i, b in enumerate(self.blocks):
+            self.desc.blocks[i] = b.data_ptr()
+        self.desc.rows_in_block = self.rows_in_block
+        self.desc.num_rows = self.rows
+        self.desc.num_cols = self.cols
+        self.desc.num_blocks = len(self.blocks)
+
+    def Rows(self):
+        return self.rows
+
+    def Cols(self):
+        return self.cols
+
+    def RowsPerBlock(self):
+        return self.rows_in_block
+
+    def Blocks(self):
+        return self.blocks
+
+    def load(self, host):
+        host = np.ascontiguousarray(host).reshape(self.rows, self.cols)
+        r = 0
+        for b in self.blocks:
+            b.copy_(self.ctx.from_numpy(host[r:r + b.shape[0]]))
+            r += b.shape[0]
+
+    def host(self):
+        return np.concatenate([to_numpy(b) for b in self.blocks], axis=0)
+
+    def gather_rows(self, rows):
+        """rows (device int64 tensor) -> [len, cols] tensor; single-block fast path."""
+        if len(self.blocks) == 1:
+            return self.blocks[0][rows]
+        return torch.cat(self.blocks, 0)[rows]
+
+
+def RandomGammaAndNormalize(ctx, eta0, eta1, pi, phi_sum, seed=(11, 113)):
+    """random.cc:159-167: N*32 streams seeded {11,113}; pi rows ~ Gamma, normalised; phi_sum = sums."""
+    rnd = Random(ctx, pi.Rows() * 32, seed)
+    ctx.check(ctx.lib.ammsb_pi_init_gamma(ctx.handle, C.byref(pi.desc), _ptr(phi_sum), eta0, eta1,
+                                          _ptr(rnd.seeds), _stream()))
+    return rnd
+
+
+class NeighborSampler:
+    """sample.h:16-49.  max_nodes = max(2*mini_batch, 1+MaxFanOut) sizes the buffers (sample.cc:88-97)."""
+
+    def __init__(self, ctx, max_nodes, neighbor_seed=(56, 57), wg=32):
+        self.ctx = ctx
+        self.n = ctx.params.num_node_sample
+        self.capacity = 2 * self.n
+        self.local = int(wg)
+        self.hash = ctx.empty((max_nodes, self.capacity), torch.int32)
+        self.data = ctx.empty((max_nodes, self.n), torch.int32)
+        self.rand = Random(ctx, max_nodes * self.capacity, neighbor_seed)
+        self.max_nodes = int(max_nodes)
+
+    def __call__(self, num_samples, nodes):
+        if num_samples > self.max_nodes:
+            raise AmmsbError("%d samples > buffer for %d" % (num_samples, self.max_nodes))
+        self.ctx.check(self.ctx.lib.ammsb_sample_neighbors(
+            self.ctx.handle, _ptr(self.rand.seeds), _ptr(nodes), int(num_samples), self.local,
+            _ptr(self.hash), _ptr(self.data), _stream()))
+
+    def GetHash(self):
+        return self.hash
+
+    def GetData(self):
+        return self.data
+
+    def HashCapacityPerSample(self):
+        return self.capacity
+
+    def DataSizePerSample(self):
+        return self.n
+
+
+class PhiUpdater:
+    """phi.h:10-61 / phi.cc:608-763.  mode is always the work-group form on this hardware."""
+
+    def __init__(self, ctx, beta, pi, phi, training_set, max_nodes, phi_seed=(42, 43), phi_wg_size=64,
+                 phi_disable_noise=False):
+        self.ctx, self.beta, self.pi, self.phi, self.set = ctx, beta, pi, phi, training_set
+        self.local = int(phi_wg_size)
+        self.flags = NOISE_OFF if phi_disable_noise else 0
+        self.max_nodes = int(max_nodes)
+        self.phi_vec = ctx.empty((self.max_nodes, ctx.params.K), torch.float32)
+        # phi.cc:625-629: max(2m, 1+maxdeg) * wg streams
+        self.rand = Random(ctx, self.max_nodes * self.local, phi_seed)
+        self.count_calls = 0
+
+    def update_phi(self, nodes, neighbors, n, group_begin=0, group_end=0xFFFFFFFF):
+        if n == 0:
+            raise AmmsbError("mini-batch nodes size = 0!")  # phi.cc:732
+        if n > self.max_nodes:
+            raise AmmsbError("grads too small")  # phi.cc:734-737 analogue
+        c = self.ctx
+        c.check(c.lib.ammsb_update_phi(c.handle, _ptr(self.beta), C.byref(self.pi.desc), _ptr(self.phi),
+                                       C.byref(self.set.desc), _ptr(nodes), _ptr(neighbors), int(n),
+                                       self.count_calls, _ptr(self.rand.seeds), self.local, self.flags,
+                                       int(group_begin), int(group_end), _ptr(self.phi_vec), _stream()))
+
+    def update_pi(self, nodes, n, phi_vec=None):
+        c = self.ctx
+        pv = self.phi_vec if phi_vec is None else phi_vec
+        c.check(c.lib.ammsb_update_pi(c.handle, C.byref(self.pi.desc), _ptr(self.phi), _ptr(pv),
+                                      _ptr(nodes), int(n), self.local, _stream()))
+
+    def __call__(self, mini_batch_nodes, neighbors, num_mini_batch_nodes):
+        self.count_calls += 1  # phi.cc:739
+        self.update_phi(mini_batch_nodes, neighbors, num_mini_batch_nodes)
+        self.update_pi(mini_batch_nodes, num_mini_batch_nodes)
+
+
+class BetaUpdater:
+    """beta.h:15-72 / beta.cc:236-384 (EDGE_PER_WORKGROUP)."""
+
+    def __init__(self, ctx, theta, beta, pi, training_set, beta_seed=(44, 45), beta_wg_size=256,
+                 disable_noise=False):
+        self.ctx, self.theta, self.beta, self.pi, self.set = ctx, theta, beta, pi, training_set
+        self.local = int(beta_wg_size)
+        self.flags = NOISE_OFF if disable_noise else 0
+        self.rand = Random(ctx, ctx.params.K, beta_seed)  # beta.cc:251-252
+        self.grads = ctx.zeros((2 * ctx.params.K,), torch.float32)
+        self.count_calls = 0
+
+    def calculate_grads(self, edges, num_edges, edge_begin=0, edge_end=0xFFFFFFFF, out=None):
+        c = self.ctx
+        g = self.grads if out is None else out
+        c.check(c.lib.ammsb_beta_grads(c.handle, _ptr(self.theta), _ptr(self.beta), C.byref(self.pi.desc),
+                                       C.byref(self.set.desc), _ptr(edges), int(num_edges), int(edge_begin),
+                                       int(min(edge_end, num_edges)), self.local, _ptr(g), _stream()))
+        return g
+
+    def update_theta(self, scale, grads=None):
+        c = self.ctx
+        g = self.grads if grads is None else grads
+        c.check(c.lib.ammsb_update_theta(c.handle, _ptr(self.theta), _ptr(self.beta), _ptr(g),
+                                         self.count_calls, float(scale), _ptr(self.rand.seeds), self.flags,
+                                         _stream()))
+
+    def __call__(self, edges, num_edges, scale):
+        self.count_calls += 1  # beta.cc:336
+        self.calculate_grads(edges, num_edges)
+        self.update_theta(scale)
+
+    def GetGrads(self):
+        return self.grads
+
+
+def beta_from_theta(ctx, theta, beta):
+    ctx.check(ctx.lib.ammsb_beta_from_theta(ctx.handle, _ptr(theta), _ptr(beta), _stream()))
+
+
+class PerplexityCalculator:
+    """perplexity.h:23-114 / perplexity.cc:184-274 (EDGE_PER_WORKGROUP)."""
+
+    def __init__(self, ctx, beta, pi, edges, edge_set, ppx_wg_size=64):
+        self.ctx, self.beta, self.pi, self.edges, self.set = ctx, beta, pi, edges, edge_set
+        self.local = int(ppx_wg_size)
+        self.num_edges = int(edges.numel())
+        self.ppx_per_edge = ctx.zeros((max(self.num_edges, 1),), torch.float32)  # perplexity.cc:204-205
+        self.sums = ctx.zeros((4,), torch.int64)  # ammsb_ppx_sums
+        self.count_calls = 0
+
+    def partial(self, edge_begin=0, edge_end=0xFFFFFFFF):
+        """Enqueue one pass over edges [edge_begin, edge_end); returns the device sums tensor."""
+        c = self.ctx
+        c.check(c.lib.ammsb_perplexity(c.handle, _ptr(self.beta), C.byref(self.pi.desc), C.byref(self.set.desc),
+                                       _ptr(self.edges), self.num_edges, int(edge_begin),
+                                       int(min(edge_end, self.num_edges)), self.count_calls, self.local,
+                                       _ptr(self.ppx_per_edge), _ptr(self.sums), _stream()))
+        return self.sums
+
+    @staticmethod
+    def unpack(sums):
+        raw = to_numpy(sums)
+        ll = raw[:2].view(np.float64)
+        cnt = raw[2:].view(np.uint64)
+        return float(ll[0]), float(ll[1]), int(cnt[0]), int(cnt[1])
+
+    @staticmethod
+    def value(link_ll, nonlink_ll, link_cnt, nonlink_cnt):
+        avg = 0.0
+        if link_cnt + nonlink_cnt != 0:  # perplexity.cc:264-268
+            avg = (link_ll + nonlink_ll) / (link_cnt + nonlink_cnt)
+        return -avg
+
+    def __call__(self):
+        self.count_calls += 1  # perplexity.cc:252
+        return self.value(*self.unpack(self.partial()))

@@ -1,0 +1,462 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: integer / index / RNG-state work is bit-exact.  Floating point: the contract of
+BASELINE.json's north_star is 1e-5 relative on pi / beta / perplexity; because the kernels keep the
+reference's lane ownership, summation tree and operation order, most float results are in fact
+bit-identical to the oracle and the tests say so where that holds (FLOAT_TOL stays the stated bar).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_TOL = 1e-5  # north_star: "within 1e-5 relative on pi/beta and perplexity"
+
+LENGTHS = [1, 2, 3, 4, 5, 6, 7, 11, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 1023, 1024, 11331]
+WGS = [2, 4, 16, 32, 64, 96, 113]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no fallback path exists)")
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import ops
+    return ops
+
+
+def rel_err(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+
+
+def elem_rel_err(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    return (np.abs(got - want) / np.maximum(np.abs(want), 1e-300)).max()
+
+
+class Problem:
+    """One seeded problem instance mirrored on the host (oracle) and on the device."""
+
+    def __init__(self, orc, hip, N, K, n, n_nodes, seed=5, deg=16, rows_in_block=0, link_frac=0.5):
+        import torch
+        self.torch = torch
+        self.orc, self.hip = orc, hip
+        rng = np.random.default_rng(seed)
+        self.rng = rng
+        self.N, self.K, self.n = N, K, n
+        self.p_orc = orc.make_params(N, K, n)
+        self.p = hip.make_params(N, K, E=deg * N, num_node_sample=n)
+        for f in ("alpha", "a", "b", "c", "epsilon", "eta0", "eta1"):
+            assert getattr(self.p, f) == getattr(self.p_orc, f)
+        self.ctx = hip.Context(self.p)
+        # state
+        self.pi_h, self.phi_sum_h = orc.pi_init_gamma(N, K)
+        self.theta_h = rng.gamma(1.0, 1.0, size=2 * K).astype(np.float32)
+        self.beta_h = np.zeros_like(self.theta_h)
+        orc.lib().orc_beta_from_theta(self.theta_h, self.beta_h, K)
+        self.edges = orc.random_graph_edges(rng, N, deg * N)
+        self.oset = orc.OracleSet(self.edges)
+        # mini-batch
+        self.nodes_h = rng.permutation(N)[:n_nodes].astype(np.uint32) if n_nodes <= N else \
+            rng.integers(0, N, size=n_nodes, dtype=np.uint32)
+        nb = rng.integers(0, N, size=(n_nodes, n), dtype=np.uint32)
+        # make ~link_frac of the entries real neighbours so both y branches are taken
+        order = np.argsort(self.edges >> np.uint64(32), kind="stable")
+        src = (self.edges >> np.uint64(32)).astype(np.uint32)[order]
+        dst = (self.edges & np.uint64(0xFFFFFFFF)).astype(np.uint32)[order]
+        lo = np.searchsorted(src, self.nodes_h, "left")
+        hi = np.searchsorted(src, self.nodes_h, "right")
+        for i in range(min(n_nodes, 4096)):
+            k = min(int(n * link_frac), hi[i] - lo[i])
+            nb[i, :k] = dst[lo[i]:lo[i] + k]
+        same = nb == self.nodes_h[:, None]
+        nb[same] = (nb[same] + 1) % N
+        self.nb_h = nb
+        # device copies
+        c = self.ctx
+        self.pi = hip.RowPartitionedMatrix(c, N, K, rows_in_block)
+        self.pi.load(self.pi_h)
+        self.phi_sum = c.from_numpy(self.phi_sum_h)
+        self.theta = c.from_numpy(self.theta_h)
+        self.beta = c.from_numpy(self.beta_h)
+        self.dset = hip.DeviceSet(c, self.oset.slots, self.oset.num_bins, self.oset.prime_idx)
+        self.nodes = c.from_numpy(self.nodes_h)
+        self.nb = c.from_numpy(self.nb_h)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ RNG / set / primitives
+
+def test_rng_seed_layout_and_normals(orc, hip):
+    p = hip.make_params(1000, 32)
+    ctx = hip.Context(p)
+    rnd = hip.Random(ctx, 1000, (42, 43))
+    h = rnd.host()
+    i = np.arange(1000, dtype=np.uint64)
+    assert np.array_equal(h["x"], 42 + i) and np.array_equal(h["y"], 43 + i)  # random-test.cc:60-63
+    import torch
+    per = 2000
+    out = ctx.empty((1000, per), torch.float32)
+    ctx.check(ctx.lib.ammsb_randn_fill(ctx.handle, C.c_void_p(rnd.seeds.data_ptr()), 1000, per,
+                                       C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    seeds = orc.rng_init(1000, 42, 43)
+    want = np.zeros((1000, per), dtype=np.float32)
+    for s in range(1000):
+        orc.lib().orc_fill_randn(seeds[s:s + 1], want[s], per)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # 2M normals, bit-exact
+    assert np.array_equal(rnd.host(), seeds)                          # and identical stream states
+    assert np.abs(got).max() > 4.0                                    # tail branch exercised
+
+
+def test_cuckoo_membership(orc, hip):
+    # cuckoo-test.cc:55-115 OpenClCuckooSetTest.RandomMembership (2M random u64 keys)
+    rng = np.random.default_rng(1)
+    keys = np.unique(rng.integers(0, 2**64 - 1, size=2 * 1024 * 1024, dtype=np.uint64))
+    rng.shuffle(keys)
+    in_len = 1 + (keys.size + 1) // 2
+    s = orc.OracleSet(keys[:in_len])
+    ctx = hip.Context(hip.make_params(1000, 32))
+    d = hip.DeviceSet(ctx, s.slots, s.num_bins, s.prime_idx)
+    assert bool(d.Has(keys[:in_len]).all())
+    assert not bool(d.Has(keys[in_len:]).any())
+
+
+@pytest.mark.parametrize("wg", WGS)
+def test_wg_sum_and_normalize(orc, hip, wg):
+    import torch
+    ctx = hip.Context(hip.make_params(1000, 32))
+    rng = np.random.default_rng(wg)
+    for v in LENGTHS:
+        host = np.arange(1, v + 1, dtype=np.uint32)
+        rng.shuffle(host)
+        d = ctx.from_numpy(host)
+        out = ctx.zeros((1,), torch.int32)
+        ctx.check(ctx.lib.ammsb_wg_sum_u32(ctx.handle, C.c_void_p(d.data_ptr()), C.c_void_p(out.data_ptr()),
+                                           1, v, wg, None))
+        assert int(out.cpu().numpy().view(np.uint32)[0]) == v * (v + 1) // 2  # wg-sum-test.cc:43
+        f = rng.standard_normal(v).astype(np.float32)
+        df = ctx.from_numpy(f)
+        of = ctx.zeros((1,), torch.float32)
+        ctx.check(ctx.lib.ammsb_wg_sum_f32(ctx.handle, C.c_void_p(df.data_ptr()), C.c_void_p(of.data_ptr()),
+                                           1, v, wg, None))
+        assert of.cpu().numpy()[0] == orc.lib().orc_wg_sum_f32(f, v, wg)  # same tree, same bits
+        nf = np.arange(1, v + 1, dtype=np.float32)
+        dn = ctx.from_numpy(nf)
+        sums = ctx.zeros((1,), torch.float32)
+        ctx.check(ctx.lib.ammsb_wg_normalize_f32(ctx.handle, C.c_void_p(dn.data_ptr()),
+                                                 C.c_void_p(sums.data_ptr()), 1, v, wg, None))
+        want = nf.copy()
+        s = orc.lib().orc_wg_normalize_f32(want, v, wg)
+        assert np.array_equal(dn.cpu().numpy(), want) and sums.cpu().numpy()[0] == s
+        total = np.float32((v * (v + 1)) / 2.0)  # wg-normalize-test.cc:43-46, 4 ULP
+        ref = (np.arange(1, v + 1, dtype=np.float32) / total).astype(np.float32)
+        ulp = np.abs(dn.cpu().numpy().view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 4
+
+
+def test_wg_sum_many_rows(hip):
+    # wg-sum-test.cc:53-78: 1024 rows of 1..1024, wg 32
+    import torch
+    ctx = hip.Context(hip.make_params(1000, 32))
+    host = np.tile(np.arange(1, 1025, dtype=np.uint32), (1024, 1))
+    d = ctx.from_numpy(host)
+    out = ctx.zeros((1024,), torch.int32)
+    ctx.check(ctx.lib.ammsb_wg_sum_u32(ctx.handle, C.c_void_p(d.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       1024, 1024, 32, None))
+    assert (out.cpu().numpy().view(np.uint32) == 1024 * 1025 // 2).all()
+
+
+def test_wg_sort(orc, hip):
+    import torch
+    ctx = hip.Context(hip.make_params(1000, 32))
+    rng = np.random.default_rng(7)
+    for n in (2, 64, 256, 1024):  # wg-sort-test.cc:23-44 uses 256
+        a = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+        a[::7] = a[0]
+        d = ctx.from_numpy(a)
+        o = ctx.zeros((n,), torch.int32)
+        ctx.check(ctx.lib.ammsb_wg_sort_u32(ctx.handle, C.c_void_p(d.data_ptr()), C.c_void_p(o.data_ptr()), n, None))
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), np.sort(a))
+        f = rng.standard_normal(n).astype(np.float32)
+        df = ctx.from_numpy(f)
+        of = ctx.zeros((n,), torch.float32)
+        ctx.check(ctx.lib.ammsb_wg_sort_f32(ctx.handle, C.c_void_p(df.data_ptr()), C.c_void_p(of.data_ptr()), n, None))
+        assert np.array_equal(of.cpu().numpy(), np.sort(f))
+
+
+def test_partitioned_matrix(orc, hip):
+    # test-partitioned-alloc.cc + wg-sum-test.cc:101-130 + wg-normalize-test.cc:135-168: 11+1 blocks
+    import torch
+    rows = cols = 1000
+    rib = rows // 11
+    ctx = hip.Context(hip.make_params(rows, cols))
+    m = hip.RowPartitionedMatrix(ctx, rows, cols, rib)
+    assert len(m.Blocks()) == 12
+    assert all(b.shape[0] == rib for b in m.Blocks()[:-1]) and m.Blocks()[-1].shape[0] == rows - 11 * rib
+    host = np.random.default_rng(0).integers(0, 2**31, size=(rows, cols)).astype(np.int32)
+    m.load(host.view(np.float32))
+    out = ctx.zeros((2,), torch.int32)
+    for r, c in ((0, 0), (rib - 1, 997), (rib, 5), (7 * rib + 3, 500), (999, 997)):
+        ctx.check(ctx.lib.ammsb_rpm_fetch(ctx.handle, C.byref(m.desc), r, c, C.c_void_p(out.data_ptr()), None))
+        assert np.array_equal(out.cpu().numpy(), host[r, c:c + 2])
+    ramp = np.tile(np.arange(1, cols + 1, dtype=np.float32), (rows, 1))
+    m.load(ramp)
+    sums = ctx.zeros((rows,), torch.float32)
+    ctx.check(ctx.lib.ammsb_rpm_sum_f32(ctx.handle, C.byref(m.desc), C.c_void_p(sums.data_ptr()), 32, None))
+    assert (sums.cpu().numpy() == cols * (cols + 1) // 2).all()
+    ctx.check(ctx.lib.ammsb_rpm_normalize_f32(ctx.handle, C.byref(m.desc), C.c_void_p(sums.data_ptr()), 32, None))
+    want = np.arange(1, cols + 1, dtype=np.float32)
+    s = orc.lib().orc_wg_normalize_f32(want, cols, 32)
+    assert np.array_equal(m.host(), np.tile(want, (rows, 1))) and (sums.cpu().numpy() == s).all()
+
+
+# ------------------------------------------------------------------------- init / sampler
+
+@pytest.mark.parametrize("N,K,rib", [(300, 96, 0), (1000, 33, 91), (70000, 32, 0)])
+def test_pi_init_gamma(orc, hip, N, K, rib):
+    import torch
+    ctx = hip.Context(hip.make_params(N, K))
+    pi = hip.RowPartitionedMatrix(ctx, N, K, rib)
+    phi = ctx.zeros((N,), torch.float32)
+    hip.RandomGammaAndNormalize(ctx, 1.0, 1.0, pi, phi)
+    torch.cuda.synchronize()
+    want_pi, want_phi = orc.pi_init_gamma(N, K)
+    assert np.array_equal(pi.host().view(np.uint32), want_pi.view(np.uint32))  # incl. N > 65535 (2 rows/group)
+    assert np.array_equal(phi.cpu().numpy(), want_phi)
+
+
+@pytest.mark.parametrize("N,n,wg,n_nodes", [(12000, 20, 32, 65536), (1000, 32, 64, 100), (5000, 8, 32, 70001)])
+def test_neighbor_sampler(orc, hip, N, n, wg, n_nodes):
+    # wg-sample-test.cc:22-72 shape (N=12000, n=20, 64k samples) + bit-exactness vs the oracle
+    import torch
+    p = hip.make_params(N, 32, num_node_sample=n)
+    ctx = hip.Context(p)
+    rng = np.random.default_rng(3)
+    nodes_h = rng.integers(0, N, size=n_nodes, dtype=np.uint32)
+    nodes = ctx.from_numpy(nodes_h)
+    smp = hip.NeighborSampler(ctx, n_nodes, (56, 57), wg)
+    seeds = orc.rng_init(n_nodes * 2 * n, 56, 57)
+    for _ in range(2):
+        smp(n_nodes, nodes)
+        torch.cuda.synchronize()
+        table, packed = orc.sample_neighbors(seeds, nodes_h, N, n, wg)
+        assert np.array_equal(smp.GetHash().cpu().numpy().view(np.uint32), table)
+        assert np.array_equal(smp.GetData().cpu().numpy().view(np.uint32), packed)
+        assert np.array_equal(smp.rand.host(), seeds)
+    got = smp.GetData().cpu().numpy().view(np.uint32)
+    assert (got != nodes_h[:, None]).all() and got.max() < N
+    srt = np.sort(got, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()  # n distinct ids per node
+
+
+# ------------------------------------------------------------------------------ phi / pi
+
+PHI_CASES = [
+    # N,    K,   n, nodes, L
+    (2048, 64, 8, 300, 64),
+    (2048, 64, 8, 300, 32),
+    (2048, 32, 8, 300, 64),     # K < L: half the lanes idle
+    (2048, 256, 32, 200, 64),
+    (2048, 256, 32, 200, 128),
+    (2048, 256, 32, 200, 256),
+    (1024, 1000, 5, 64, 64),    # K not a multiple of L, odd n
+    (1024, 1024, 32, 64, 64),   # the C3 row shape
+    (1024, 1024, 32, 64, 256),
+    (512, 4096, 4, 16, 256),    # the C5 row shape
+    (4096, 512, 4, 4096, 32),   # wg-phi-test.cc:116-142 shape (N=4096, K=512, n=4, all nodes)
+]
+
+
+@pytest.mark.parametrize("N,K,n,n_nodes,L", PHI_CASES)
+@pytest.mark.parametrize("noise", [False, True])
+def test_update_phi_and_pi(orc, hip, N, K, n, n_nodes, L, noise):
+    pr = Problem(orc, hip, N, K, n, n_nodes)
+    upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L,
+                         phi_disable_noise=not noise)
+    seeds = orc.rng_init(n_nodes * L, 42, 43)
+    pi_h, phi_sum_h = pr.pi_h.copy(), pr.phi_sum_h.copy()
+    for step in (1, 2):  # second call consumes the carried-over stream states
+        upd(pr.nodes, pr.nb, n_nodes)
+        pr.sync()
+        want = orc.update_phi(pr.p_orc, pr.beta_h, pi_h.reshape(-1), phi_sum_h, pr.oset, pr.nodes_h,
+                              pr.nb_h.reshape(-1), step, seeds, L, 1, noise)
+        got = upd.phi_vec.cpu().numpy()[:n_nodes]
+        assert elem_rel_err(got, want) <= FLOAT_TOL
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "expected bit-identical phi_vec"
+        assert np.array_equal(upd.rand.host(), seeds)
+        orc.update_pi(pr.p_orc, pi_h.reshape(-1), phi_sum_h, want.reshape(-1), pr.nodes_h, L, 1)
+        assert np.array_equal(pr.pi.host().view(np.uint32), pi_h.view(np.uint32))
+        assert np.array_equal(pr.phi_sum.cpu().numpy(), phi_sum_h)
+    assert np.allclose(pr.pi.host()[pr.nodes_h].sum(1), 1.0, atol=2e-6)
+
+
+def test_update_phi_more_nodes_than_groups(orc, hip):
+    # n_nodes > 65535: groups 0.. handle two nodes each and carry their stream state (phi.cc:292-300)
+    N, K, n, L = 70000, 32, 4, 32
+    n_nodes = 65535 + 1500
+    pr = Problem(orc, hip, N, K, n, n_nodes, deg=4)
+    upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L)
+    seeds = orc.rng_init(n_nodes * L, 42, 43)
+    upd(pr.nodes, pr.nb, n_nodes)
+    pr.sync()
+    want = orc.update_phi(pr.p_orc, pr.beta_h, pr.pi_h.reshape(-1), pr.phi_sum_h, pr.oset, pr.nodes_h,
+                          pr.nb_h.reshape(-1), 1, seeds, L, 1, True)
+    assert np.array_equal(upd.phi_vec.cpu().numpy()[:n_nodes].view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(upd.rand.host(), seeds)
+
+
+def test_update_phi_group_shards(orc, hip):
+    # multi-GPU shard contract: disjoint group ranges reproduce the single-call result exactly
+    N, K, n, L, n_nodes = 2048, 128, 8, 64, 777
+    pr = Problem(orc, hip, N, K, n, n_nodes)
+    full = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L)
+    full.count_calls = 1
+    full.update_phi(pr.nodes, pr.nb, n_nodes)
+    part = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L)
+    part.count_calls = 1
+    part.phi_vec.zero_()
+    for lo, hi in ((0, 100), (100, 101), (101, 600), (600, 5000)):
+        part.update_phi(pr.nodes, pr.nb, n_nodes, lo, hi)
+    pr.sync()
+    assert np.array_equal(full.phi_vec.cpu().numpy()[:n_nodes], part.phi_vec.cpu().numpy()[:n_nodes])
+    assert np.array_equal(full.rand.host(), part.rand.host())
+
+
+def test_update_phi_partitioned_pi(orc, hip):
+    N, K, n, L, n_nodes = 1000, 64, 8, 64, 200
+    a = Problem(orc, hip, N, K, n, n_nodes)
+    b = Problem(orc, hip, N, K, n, n_nodes, rows_in_block=N // 11)
+    assert len(b.pi.Blocks()) == 12
+    ua = hip.PhiUpdater(a.ctx, a.beta, a.pi, a.phi_sum, a.dset, n_nodes, (42, 43), L)
+    ub = hip.PhiUpdater(b.ctx, b.beta, b.pi, b.phi_sum, b.dset, n_nodes, (42, 43), L)
+    ua(a.nodes, a.nb, n_nodes)
+    ub(b.nodes, b.nb, n_nodes)
+    a.sync()
+    assert np.array_equal(a.pi.host(), b.pi.host())
+
+
+# --------------------------------------------------------------------------- beta / theta
+
+BETA_CASES = [(2048, 64, 500, 64), (2048, 64, 500, 32), (2048, 256, 3000, 128), (1024, 1000, 300, 256),
+              (4096, 1024, 1024, 64), (4096, 1024, 1024, 256), (4096, 1024, 1024, 1024)]  # wg-beta-test.cc shape
+
+
+@pytest.mark.parametrize("N,K,n_edges,L", BETA_CASES)
+def test_beta_pipeline(orc, hip, N, K, n_edges, L):
+    pr = Problem(orc, hip, N, K, 8, 16)
+    rng = pr.rng
+    non = orc.make_edge(rng.integers(0, N, n_edges), rng.integers(0, N, n_edges))
+    mbe = np.concatenate([pr.edges[: n_edges // 3], non[: n_edges - n_edges // 3]]).astype(np.uint64)
+    rng.shuffle(mbe)
+    dev_edges = pr.ctx.from_numpy(mbe)
+    upd = hip.BetaUpdater(pr.ctx, pr.theta, pr.beta, pr.pi, pr.dset, (44, 45), L)
+    seeds = orc.rng_init(K, 44, 45)
+    theta_h, beta_h = pr.theta_h.copy(), pr.beta_h.copy()
+    for step in (1, 2):
+        upd.count_calls += 1
+        g = upd.calculate_grads(dev_edges, mbe.size)
+        pr.sync()
+        got_g = g.cpu().numpy().copy()
+        exact = orc.beta_grads(pr.p_orc, theta_h, beta_h, pr.pi_h.reshape(-1), pr.oset, mbe, L, 1, order=1)
+        ref = orc.beta_grads(pr.p_orc, theta_h, beta_h, pr.pi_h.reshape(-1), pr.oset, mbe, L, 1, order=0)
+        # the sum over edges is order-free by contract: compare against the float64 accumulation of the
+        # oracle's per-edge float32 terms, and require the HIP sum to be at least as close to it as
+        # the reference's own serial order is.
+        assert rel_err(got_g, exact) <= FLOAT_TOL
+        assert rel_err(got_g, exact) <= max(2 * rel_err(ref, exact), 2e-7)
+        # theta step on the HIP gradient: bit-exact given the same inputs
+        upd.update_theta(0.01)
+        pr.sync()
+        beta_h = orc.update_theta(pr.p_orc, theta_h, got_g, step, 0.01, seeds)
+        assert np.array_equal(pr.theta.cpu().numpy().view(np.uint32), theta_h.view(np.uint32))
+        assert np.array_equal(pr.beta.cpu().numpy().view(np.uint32), beta_h.view(np.uint32))
+        assert np.array_equal(upd.rand.host(), seeds)
+
+
+def test_beta_grads_edge_shards(orc, hip):
+    N, K, L = 2048, 128, 64
+    pr = Problem(orc, hip, N, K, 8, 16)
+    mbe = pr.edges[:1000].copy()
+    dev_edges = pr.ctx.from_numpy(mbe)
+    upd = hip.BetaUpdater(pr.ctx, pr.theta, pr.beta, pr.pi, pr.dset, (44, 45), L)
+    full = upd.calculate_grads(dev_edges, mbe.size).clone()
+    acc = np.zeros(2 * K, dtype=np.float64)
+    for lo, hi in ((0, 250), (250, 251), (251, 1000), (1000, 1000)):
+        acc += upd.calculate_grads(dev_edges, mbe.size, lo, hi).cpu().numpy().astype(np.float64)
+    assert rel_err(acc, full.cpu().numpy()) <= 2e-6
+
+
+# ----------------------------------------------------------------------------- perplexity
+
+@pytest.mark.parametrize("N,K,L", [(1024, 1024, 64), (1024, 1024, 256), (1024, 1024, 1024), (2048, 96, 32),
+                                   (2048, 1000, 128)])
+def test_perplexity(orc, hip, N, K, L):
+    # wg-perplexity-test.cc:86-108 shape: N=1024, K=1024, ~1024 held-out edges
+    pr = Problem(orc, hip, N, K, 8, 16)
+    held = pr.edges[:600]
+    hset = orc.OracleSet(held)
+    fake = orc.make_edge(pr.rng.integers(0, N, 600), pr.rng.integers(0, N, 600))
+    he = np.concatenate([held, fake[~hset.has(fake)]]).astype(np.uint64)
+    dh = hip.DeviceSet(pr.ctx, hset.slots, hset.num_bins, hset.prime_idx)
+    calc = hip.PerplexityCalculator(pr.ctx, pr.beta, pr.pi, pr.ctx.from_numpy(he), dh, L)
+    state = np.zeros(he.size, dtype=np.float32)
+    for call in (1, 2, 3):
+        got = calc()
+        pr.sync()
+        sums, ll = orc.perplexity(pr.p_orc, pr.beta_h, pr.pi_h.reshape(-1), hset, he, call, L, 1, state, want_ll=True)
+        assert np.array_equal(calc.ppx_per_edge.cpu().numpy().view(np.uint32), state.view(np.uint32))
+        l0, l1, c0, c1 = calc.unpack(calc.sums)
+        assert (c0, c1) == (sums.link_cnt, sums.nonlink_cnt)
+        assert abs(l0 - sums.link_ll) <= 1e-12 * abs(sums.link_ll)
+        assert abs(l1 - sums.nonlink_ll) <= 1e-12 * abs(sums.nonlink_ll)
+        want = -(sums.link_ll + sums.nonlink_ll) / (sums.link_cnt + sums.nonlink_cnt)
+        assert abs(got - want) <= FLOAT_TOL * abs(want)
+        assert abs(np.exp(got) - orc.lib().orc_ppx_value(sums)) <= FLOAT_TOL * np.exp(got)
+        # changing pi between calls exercises the running mean (perplexity.cc:51-52)
+        pr.pi_h[:] = np.roll(pr.pi_h, 1, axis=0)
+        pr.pi.load(pr.pi_h)
+
+
+def test_perplexity_shards(orc, hip):
+    N, K, L = 1024, 128, 64
+    pr = Problem(orc, hip, N, K, 8, 16)
+    he = pr.edges[:999].copy()
+    hset = orc.OracleSet(he[:500])
+    dh = hip.DeviceSet(pr.ctx, hset.slots, hset.num_bins, hset.prime_idx)
+    a = hip.PerplexityCalculator(pr.ctx, pr.beta, pr.pi, pr.ctx.from_numpy(he), dh, L)
+    b = hip.PerplexityCalculator(pr.ctx, pr.beta, pr.pi, pr.ctx.from_numpy(he), dh, L)
+    a.count_calls = b.count_calls = 1
+    fa = a.unpack(a.partial())
+    parts = [b.unpack(b.partial(lo, hi)) for lo, hi in ((0, 333), (333, 334), (334, 999))]
+    assert sum(p[2] for p in parts) == fa[2] and sum(p[3] for p in parts) == fa[3]
+    assert abs(sum(p[0] for p in parts) - fa[0]) <= 1e-10 * abs(fa[0])
+    assert np.array_equal(a.ppx_per_edge.cpu().numpy(), b.ppx_per_edge.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------- error paths
+
+def test_error_behaviour(orc, hip):
+    pr = Problem(orc, hip, 1024, 2048, 4, 8)
+    upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, 8, (42, 43), 64)
+    with pytest.raises(hip.AmmsbError, match="mini-batch nodes size = 0"):  # phi.cc:732 LOG(FATAL)
+        upd(pr.nodes, pr.nb, 0)
+    upd.local = 96
+    with pytest.raises(hip.AmmsbError, match="invalid argument"):
+        upd(pr.nodes, pr.nb, 8)
+    upd.local = 32  # K=2048 needs 64 columns per lane at wg 32: beyond the register-resident forms
+    with pytest.raises(hip.AmmsbError, match="out of range"):
+        upd(pr.nodes, pr.nb, 8)
+    lib = pr.ctx.lib
+    assert lib.ammsb_update_phi(None, None, None, None, None, None, None, 1, 1, None, 64, 0, 0, 1, None, None) == -1
+    assert lib.ammsb_strerror(-2) == b"HIP runtime error"
