@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mini-batch edges/s of the SG-MCMC a-MMSB learner loop (+ perplexity-eval ms).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], "C3"): synthetic a-MMSB graph N = 1M vertices, average degree 32,
+K = 1024 communities, mini-batch m = 65536, n = 32 neighbour samples, held-out ratio 0.01, strategy
+Node (a fair coin picks a link batch = all edges of one vertex, or a non-link batch = m non-links of
+one vertex).  A step is one Learner iteration: mini-batch + neighbour sampling, update_phi, update_pi,
+the beta gradient and the theta/beta update.  With N > 1 the same problem is sharded (strong scaling).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # name: (N, K, m, n, avg_degree, K_true)
+    "C1": (10_000, 32, 1024, 32, 32, 32),
+    "C2": (100_000, 256, 8192, 32, 32, 64),
+    "C3": (1_000_000, 1024, 65536, 32, 32, 64),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--phi-wg", type=int, default=0)
+    ap.add_argument("--beta-wg", type=int, default=0)
+    ap.add_argument("--ppx-wg", type=int, default=0)
+    ap.add_argument("--host-sampling", action="store_true",
+                    help="reference-exact host mini-batch sampler (rand_r) instead of the device sampler")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="nodes/edges in the CPU-baseline sample")
+    ap.add_argument("--ppx-calls", type=int, default=5)
+    return ap.parse_args()
+
+
+def pick_wg(K, override, cap):
+    if override:
+        return override
+    wg = 64
+    while K // wg > cap and wg < 1024:  # keep <= cap columns per lane
+        wg *= 2
+    return wg
+
+
+def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
+    """The reference's CPU path (per-thread kernels, learner.cc:105-114) restated in oracle/, timed on
+    the host cores of this box on a bounded slice of one non-link mini-batch."""
+    import torch
+    import oracle_lib as orc
+    native = os.path.join(ROOT, "oracle", "libammsb_oracle_native.so")
+    try:
+        orc.build(native, "-march=native")
+        lib_path = native
+    except Exception:
+        lib_path = None
+    L = orc.lib(lib_path) if lib_path else orc.lib()
+    import ctypes as C
+    cores = L.orc_num_threads()
+    K, n = cfg.K, cfg.num_node_sample
+    s = args.cpu_sample or max(256, min(4096, (24 * cores * 64) // max(K // 64, 1)))
+    s = min(s, n_nodes_big - 1)
+    rng = np.random.default_rng(1)
+    p = orc.make_params(cfg.N, K, n, alpha=np.float32(cfg.alpha))
+    pi_h = lrn.pi.host()
+    phi_h = lrn.phi.cpu().numpy().copy()
+    beta_h = lrn.beta.cpu().numpy().copy()
+    theta_h = lrn.theta.cpu().numpy().copy()
+    tset = ds.training
+    slots, bins, pidx = tset.Serialize(), tset.BinsPerBucket(), tset.PrimeIdx()
+    u = int(rng.integers(0, cfg.N))
+    vs = rng.permutation(cfg.N)[:s].astype(np.uint32)
+    nodes = vs.copy()
+    nbrs = rng.integers(0, cfg.N, size=(s, n), dtype=np.uint32)
+    edges = orc.make_edge(np.full(s, u, dtype=np.uint64), vs.astype(np.uint64))
+    seeds = orc.rng_init(s, 42, 43)
+    phi_vec = np.zeros((s, K), dtype=np.float32)
+    grads = np.zeros(2 * K, dtype=np.float32)
+    theta_sum = np.zeros(K, dtype=np.float32)
+    t0 = time.perf_counter()
+    L.orc_update_phi(C.byref(p), beta_h, pi_h.reshape(-1), phi_h, slots, bins, pidx, nodes, nbrs.reshape(-1), s, 1,
+                     seeds, 32, 0, 1, phi_vec.reshape(-1))
+    L.orc_update_pi(C.byref(p), pi_h.reshape(-1), phi_h, phi_vec.reshape(-1), nodes, s, 32, 0)
+    L.orc_sum_theta(theta_h, theta_sum, K)
+    L.orc_beta_grads(C.byref(p), theta_h, theta_sum, beta_h, pi_h.reshape(-1), slots, bins, pidx, edges, s, 32, 0, 0,
+                     grads)
+    L.orc_update_theta(C.byref(p), theta_h, grads, 1, np.float32(1.0), orc.rng_init(K, 44, 45), 1)
+    dt = time.perf_counter() - t0
+    return {"value": s / dt, "unit": "mini-batch edges/s", "cores": int(cores), "kind": "port",
+            "sample": "%d of the %d nodes and %d of the %d edges of one non-link mini-batch (phi+pi+beta, "
+                      "per-thread kernels, OpenMP over nodes/edges, %.1f s)" % (s, n_nodes_big, s, cfg.mini_batch_size, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib
+    from mcmc_ammsb_gpu_amd.learner import Config, Learner
+
+    N, K, m, n, deg, k_true = WORKLOADS[args.workload]
+    t_setup = time.perf_counter()
+    edges = hostlib.generate_graph(N, k_true, deg, seed=20260101)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.01, rand_seed=1)
+    cfg = Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, strategy="Node",
+                                   phi_wg_size=pick_wg(K, args.phi_wg, 4),
+                                   beta_wg_size=pick_wg(K, args.beta_wg, 4),
+                                   ppx_wg_size=pick_wg(K, args.ppx_wg, 8),
+                                   device_sampling=not args.host_sampling)
+    lrn = Learner(cfg, ds, rank=rank, world_size=world)
+    setup_s = time.perf_counter() - t_setup
+
+    def sync():
+        lrn.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- perplexity latency (mean of --ppx-calls, after one untimed call)
+    lrn.HeldoutPerplexity()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.ppx_calls):
+        ppx = lrn.HeldoutPerplexity()
+    sync()
+    ppx_ms = (time.perf_counter() - t0) * 1e3 / max(args.ppx_calls, 1)
+
+    # ---- warm-up, then EXACTLY --steps timed iterations
+    lrn.Run(args.warmup)
+    sync()
+    # HIP-event timing of the dominant kernel (update_phi) on its launch stream, inside the timed region
+    phi = lrn.phiUpdater
+    ev = []
+    orig = phi.update_phi
+
+    def timed_update_phi(nodes, neighbors, nn, lo=0, hi=0xFFFFFFFF):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream())
+        orig(nodes, neighbors, nn, lo, hi)
+        b.record(torch.cuda.current_stream())
+        ev.append((a, b, nn, max(0, min(hi, min(nn, 65535)) - lo)))
+
+    phi.update_phi = timed_update_phi
+    edges_before = lrn.edges_done
+    sync()
+    t0 = time.perf_counter()
+    lrn.Run(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    phi.update_phi = orig
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    edges_done = lrn.edges_done - edges_before  # identical on every rank: the whole job's mini-batch edges
+
+    # roofline of update_phi over the big (non-link) launches of the timed region
+    big = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev if nn > m // 2]
+    roofline = None
+    if big:
+        per_node = 4 * K * (n + 2) + 68 * n + 8  # algorithmic bytes of update_phi per mini-batch node
+        nodes_per_launch = float(np.mean([g for _, _, g in big]))  # nodes this rank's launch processed
+        avg_s = float(np.mean([t for t, _, _ in big]))
+        achieved = per_node * nodes_per_launch / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "phi_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "update_phi_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": len(big),
+                    "bytes_per_launch": int(per_node * nodes_per_launch)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args, lrn, cfg, ds, m + 1)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
+            cpu = {"value": None, "unit": "mini-batch edges/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    if rank == 0:
+        out = {
+            "metric": "mini-batch edges/s (SG-MCMC a-MMSB learner loop)",
+            "value": edges_done / dt,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: synthetic a-MMSB graph N=%d avg-degree=%d K=%d mini-batch=%d n=%d strategy=Node"
+                                   % (args.workload, N, deg, K, m, n),
+                       "E": int(ds.E), "heldout_edges": int(ds.heldout_edges.size),
+                       "phi_wg": cfg.phi_wg_size, "beta_wg": cfg.beta_wg_size, "ppx_wg": cfg.ppx_wg_size,
+                       "sampling": "host(rand_r)" if args.host_sampling else "device",
+                       "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world},
+            "ppx_eval_ms": ppx_ms,
+            "perplexity": ppx,
+            "mini_batch_edges": int(edges_done),
+            "setup_s": round(setup_s, 1),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    lrn.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,32 @@ int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, con
                      const uint64_t* edges, uint32_t n_edges, uint32_t edge_begin, uint32_t edge_end,
                      uint32_t call_count, uint32_t wg, float* ppx_per_edge, ammsb_ppx_sums* out, void* stream);
 
+/* ---- device-side mini-batch sampling (new; the reference samples on one host thread,
+ *      sample.cc:177-303 + learner.cc:162-185, which caps throughput once the kernels are fast) ----
+ * Strategy "Node" (stratified random node, sample.cc:295-303) split in its two halves; the caller
+ * flips the coin and picks u on the host, so that the mini-batch sizes are known without a device
+ * round trip.  Same distribution as the host samplers, not the same random stream. */
+
+/* sampleNodeLink's edge set for vertex u: all training edges (u, v), v in CSR order.  n = deg(u) =
+ * offsets[u+1] - offsets[u] must be > 0.  edges_out[n], nodes_out[n+1] = {u, v_0, ...}. */
+int ammsb_minibatch_link(ammsb_ctx* ctx, const uint64_t* csr_offsets, const uint32_t* csr_targets, uint32_t u,
+                         uint32_t n, uint64_t* edges_out, uint32_t* nodes_out, void* stream);
+
+/* number of candidate draws (= RNG streams, = workspace entries) ammsb_minibatch_nonlink needs for
+ * m distinct non-links out of N vertices; 0 if N is too small for m (needs N >= 2m) */
+uint32_t ammsb_minibatch_candidates(uint64_t N, uint32_t m);
+/* bytes of workspace for that many candidates */
+uint64_t ammsb_minibatch_workspace_bytes(uint32_t n_candidates);
+
+/* sampleNodeNonLink: m distinct v != u with (u,v) in neither set, in candidate order (candidate j =
+ * one draw from stream j, kept if valid and the first occurrence of its v).  edges_out[m],
+ * nodes_out[m+1] = {u, v_0, ...}; count_out[0] = number of distinct valid candidates found (>= m
+ * unless the draw was exceptionally unlucky, in which case the tail repeats earlier entries and
+ * count_out[0] < m tells the caller).  heldout_set may be NULL. */
+int ammsb_minibatch_nonlink(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_candidates, uint32_t u, uint32_t m,
+                            const ammsb_set* training_set, const ammsb_set* heldout_set, void* workspace,
+                            uint64_t* edges_out, uint32_t* nodes_out, uint32_t* count_out, void* stream);
+
 /* ---- wg_* primitives (test entry points; kernels of algorithm/{sum,normalize,sort}.cc) ---- */
 /* WG_SUM_KERNEL_TT, sum.cc:44-52: out[r] = WG_SUM(in + r*len, len) with `wg` lanes (any wg in [1,1024]) */
 int ammsb_wg_sum_f32(ammsb_ctx* ctx, const float* in, float* out, uint32_t rows, uint32_t len, uint32_t wg,

@@ -1,0 +1,84 @@
+// mcmc::Config: drop-in for the reference's mcmc/config.h:25-102 (same field names, same defaults).
+#ifndef MCMC_AMD_CONFIG_H_
+#define MCMC_AMD_CONFIG_H_
+
+#include <iosfwd>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ammsb.h"
+#include "mcmc/data.h"
+#include "mcmc/sample.h"
+
+namespace mcmc {
+
+enum PhiUpdaterMode {
+  PHI_NODE_PER_THREAD,
+  PHI_NODE_PER_WORKGROUP_NAIVE,
+  PHI_NODE_PER_WORKGROUP_SHARED,
+  PHI_NODE_PER_WORKGROUP_CODE_GEN
+};
+
+std::istream& operator>>(std::istream& in, PhiUpdaterMode& mode);
+std::string to_string(const PhiUpdaterMode& mode);
+
+struct Config {
+  Float heldout_ratio;
+  Float alpha;
+  Float a, b, c;
+  Float epsilon;
+  Float eta0, eta1;
+  uint64_t K;
+  uint64_t mini_batch_size;
+  uint64_t num_node_sample;
+  uint64_t N;
+  uint64_t E;
+  std::vector<Edge> training_edges;
+  std::vector<Edge> heldout_edges;
+  std::unique_ptr<mcmc::Set> training;
+  std::unique_ptr<mcmc::Set> heldout;
+  std::unique_ptr<mcmc::Graph> trainingGraph;
+  std::unique_ptr<mcmc::Graph> heldoutGraph;
+
+  uint32_t ppx_wg_size;
+  uint32_t ppx_interval;
+  uint32_t neighbor_sampler_wg_size;
+  uint32_t phi_wg_size;
+  uint32_t beta_wg_size;
+
+  ulong2 phi_seed;
+  ulong2 beta_seed;
+  ulong2 neighbor_seed;
+
+  bool phi_disable_noise;
+
+  SampleStrategy strategy;
+
+  // Accepted for source compatibility.  All four values select the register-resident work-group
+  // kernel; THREAD (the reference's CPU-device shape) has no GPU counterpart here.
+  PhiUpdaterMode phi_mode;
+  bool phi_probs_shared;
+  bool phi_grads_shared;
+  bool phi_pi_shared;
+  uint32_t phi_vector_width;
+  uint32_t sum_grads_vector_width;
+
+  // new: draw mini-batches on the device instead of with the host samplers above
+  bool device_sampling;
+
+  Config();
+};
+
+std::ostream& operator<<(std::ostream& out, const Config& cfg);
+
+// The -D constants of MakeCompileFlags (config.cc:66-83) as the POD the C ABI takes, including the
+// "%e" round trip every float goes through there.
+ammsb_params MakeKernelParams(const Config& cfg);
+
+// kept for callers that log them; the strings match config.cc:66-83
+std::vector<std::string> MakeCompileFlags(const Config& cfg);
+
+}  // namespace mcmc
+
+#endif  // MCMC_AMD_CONFIG_H_

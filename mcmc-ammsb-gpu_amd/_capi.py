@@ -62,6 +62,10 @@ SIGNATURES = {
     "ammsb_update_theta": [_vp, _vp, _vp, _vp, _u32, _f32, _vp, _u32, _vp],
     "ammsb_beta_from_theta": [_vp, _vp, _vp, _vp],
     "ammsb_perplexity": [_vp, _vp, _P(Rpm), _P(SetDesc), _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "ammsb_minibatch_link": [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "ammsb_minibatch_candidates": [_u64, _u32],
+    "ammsb_minibatch_workspace_bytes": [_u32],
+    "ammsb_minibatch_nonlink": [_vp, _vp, _u32, _u32, _u32, _P(SetDesc), _P(SetDesc), _vp, _vp, _vp, _vp, _vp],
     "ammsb_wg_sum_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "ammsb_wg_sum_u32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "ammsb_wg_normalize_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
@@ -72,7 +76,8 @@ SIGNATURES = {
     "ammsb_randn_fill": [_vp, _vp, _u32, _u32, _vp, _vp],
     "ammsb_rpm_fetch": [_vp, _P(Rpm), _u64, _u64, _vp, _vp],
 }
-_OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_eps_t": C.c_float}
+_OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_eps_t": C.c_float,
+              "ammsb_minibatch_candidates": C.c_uint32, "ammsb_minibatch_workspace_bytes": C.c_uint64}
 
 _lib = None
 

@@ -1,0 +1,321 @@
+"""mcmc::Learner on top of the operator mirror (ops.py): same state, same per-iteration order, same
+double-buffered sampling as the reference (mcmc/learner.{h,cc}), plus the multi-GPU shard/exchange
+the reference does not have.
+
+    Learner(cfg, dataset)      learner.cc:77-156   allocate beta/theta/pi/phi, upload both sets, init
+    Run(max_iters)             learner.cc:214-250  [join sample | launch next sample] phi, pi, beta
+    HeldoutPerplexity()        learner.cc:196-203
+    PrintStats()               learner.cc:252-299
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL): pi, phi_sum, beta/theta and both
+cuckoo sets are replicated; the mini-batch is the same on every rank (same seeds).  Per iteration
+    phi    rank r runs virtual groups [r*C, (r+1)*C), C = ceil(65535/R) -- a fixed ownership of RNG
+           streams, so no stream state ever crosses ranks -- then the phi_vec rows are all-gathered
+           and every rank applies update_pi to all mini-batch nodes;
+    beta   rank r sums the gradient over its contiguous slice of the mini-batch edges; the R partial
+           [2K] vectors are all-gathered and added in rank order; every rank runs the identical
+           update_theta (same streams) -> no broadcast;
+    ppx    contiguous slices of the held-out edges; 4 scalars per rank are all-gathered.
+"""
+import concurrent.futures
+import time
+
+import numpy as np
+import torch
+
+from ._capi import AmmsbError, MAX_GROUPS
+
+
+class Config:
+    """mcmc::Config (config.h:25-102): same field names and defaults.  Extras are marked (new)."""
+
+    def __init__(self, **kw):
+        self.heldout_ratio = 0.01
+        self.alpha = 0.001
+        self.a, self.b, self.c = 0.0315, 1024.0, 0.5
+        self.epsilon = 1e-7
+        self.eta0, self.eta1 = 1.0, 1.0
+        self.K = 32
+        self.mini_batch_size = 32
+        self.num_node_sample = 32
+        self.N = 0
+        self.E = 0
+        self.ppx_wg_size = 32
+        self.ppx_interval = 100
+        self.neighbor_sampler_wg_size = 32
+        self.phi_wg_size = 32
+        self.beta_wg_size = 32
+        self.phi_seed = (42, 43)
+        self.beta_seed = (113, 117)
+        self.neighbor_seed = (3337, 54351)
+        self.phi_disable_noise = False
+        self.strategy = "Node"
+        self.sample_seeds = (1804289383, 846930886)  # (new) Sample::seed = rand() twice, sample.cc:132
+        self.device_sampling = False                 # (new) draw mini-batches on the device
+        self.device_sampling_seed = (1234, 5678)     # (new)
+        self.sample_parallel = True                  # MCMC_SAMPLE_PARALLEL, CMakeLists.txt:42
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError("unknown Config field %s" % k)
+            setattr(self, k, v)
+
+    @classmethod
+    def from_cli_defaults(cls, **kw):
+        """The reference CLI's defaults where they differ from the struct's (main.cc:43-81, :153)."""
+        base = dict(alpha=0.0, beta_seed=(44, 45), neighbor_seed=(56, 57))
+        base.update(kw)
+        return cls(**base)
+
+
+class Sample:
+    """sample.h:51-92: one of the two mini-batch buffers with its own queue (stream)."""
+
+    def __init__(self, learner, seed):
+        L = learner
+        cfg, ds, ctx = L.cfg, L.dataset, L.ctx
+        self.stream = L.ops.new_stream(ctx)
+        self.max_edges = ds.max_edges(cfg.mini_batch_size)
+        self.max_nodes = ds.max_nodes(cfg.mini_batch_size)
+        self.dev_edges = ctx.empty((self.max_edges,), torch.int64)
+        self.dev_nodes = ctx.empty((self.max_nodes,), torch.int32)
+        self.pin_edges = L.ops.pinned((self.max_edges,), torch.int64)
+        self.pin_nodes = L.ops.pinned((self.max_nodes,), torch.int32)
+        self.seed = int(seed)
+        self.edges = np.zeros(0, dtype=np.uint64)
+        self.nodes_vec = np.zeros(0, dtype=np.uint32)
+        self.n_edges = self.n_nodes = 0
+        self.neighbor_sampler = L.ops.NeighborSampler(ctx, self.max_nodes, cfg.neighbor_seed,
+                                                      cfg.neighbor_sampler_wg_size)
+        self.ready = L.ops.new_event()      # sampling finished (recorded on self.stream)
+        self.consumed = L.ops.new_event()   # the iteration that used this sample finished (main stream)
+        self.consumed_valid = False
+
+
+class Learner:
+    def __init__(self, cfg, dataset, ops=None, rank=0, world_size=1, group=None, ctx=None):
+        if ops is None:
+            from . import ops as _ops
+            ops = _ops
+        self.ops = ops
+        self.cfg, self.dataset = cfg, dataset
+        self.rank, self.world, self.group = int(rank), int(world_size), group
+        cfg.N, cfg.E = dataset.N, dataset.E
+        if cfg.alpha == 0:
+            cfg.alpha = float(np.float32(1.0) / np.float32(cfg.K))  # main.cc:153
+        self.params = ops.make_params(cfg.N, cfg.K, cfg.E, cfg.num_node_sample, cfg.alpha, cfg.a, cfg.b, cfg.c,
+                                      cfg.epsilon, cfg.eta0, cfg.eta1)
+        self.ctx = ctx if ctx is not None else ops.Context(self.params)
+        c = self.ctx
+        K, N = cfg.K, cfg.N
+        # learner.cc:80-91
+        self.beta = c.zeros((2 * K,), torch.float32)
+        self.theta = c.zeros((2 * K,), torch.float32)
+        self.pi = ops.RowPartitionedMatrix(c, N, K)
+        self.phi = c.zeros((N,), torch.float32)
+        ts, hs = dataset.training, dataset.heldout
+        self.trainingSet = ops.DeviceSet(c, ts.Serialize(), ts.BinsPerBucket(), ts.PrimeIdx())
+        self.heldoutSet = ops.DeviceSet(c, hs.Serialize(), hs.BinsPerBucket(), hs.PrimeIdx()) if hs else None
+        self.heldoutEdges = c.from_numpy(dataset.heldout_edges)
+        if self.heldoutSet is None:
+            raise AmmsbError("held-out set is empty: raise heldout_ratio")
+        max_nodes = dataset.max_nodes(cfg.mini_batch_size)
+        self.chunk = (MAX_GROUPS + self.world - 1) // self.world  # phi groups owned per rank
+        phi_rows = max(max_nodes, self.chunk * self.world if self.world > 1 else 0)
+        # learner.cc:105-116
+        self.heldoutPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.heldoutEdges,
+                                                          self.heldoutSet, cfg.ppx_wg_size)
+        self.phiUpdater = ops.PhiUpdater(c, self.beta, self.pi, self.phi, self.trainingSet, phi_rows,
+                                         cfg.phi_seed, cfg.phi_wg_size, cfg.phi_disable_noise)
+        self.betaUpdater = ops.BetaUpdater(c, self.theta, self.beta, self.pi, self.trainingSet, cfg.beta_seed,
+                                           cfg.beta_wg_size)
+        self.stepCount = 1
+        self.time = 0.0
+        self.samplingTime = 0.0
+        self.edges_done = 0
+        self.samples = [Sample(self, cfg.sample_seeds[0])]
+        if cfg.sample_parallel:
+            self.samples.append(Sample(self, cfg.sample_seeds[1]))
+        self.phase = 0
+        self.futures = [None, None]
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if not cfg.device_sampling else None
+        self.dev_sampler = None
+        if cfg.device_sampling:
+            off, tgt = dataset.training_csr()
+            self.dev_sampler = ops.DeviceMiniBatchSampler(c, off, tgt, self.trainingSet, self.heldoutSet,
+                                                          cfg.mini_batch_size, cfg.device_sampling_seed)
+        if self.world > 1:
+            self.all_grads = c.zeros((self.world, 2 * K), torch.float32)
+            self.all_sums = c.zeros((self.world, 4), torch.int64)
+        # learner.cc:150-155: theta_0 (host std::gamma) -> beta_0; pi_0 / phi_sum_0 (device gamma {11,113})
+        from . import hostlib
+        self.theta.copy_(c.from_numpy(hostlib.theta_init(K, cfg.eta0, cfg.eta1)))
+        ops.beta_from_theta(c, self.theta, self.beta)
+        ops.RandomGammaAndNormalize(c, cfg.eta0, cfg.eta1, self.pi, self.phi)
+        ops.synchronize()
+
+    # ------------------------------------------------------------------ sampling (learner.cc:175-194)
+
+    def _do_sample(self, sample):
+        """DoSample: produce a mini-batch into `sample` on its own stream; returns the weight."""
+        ops, cfg = self.ops, self.cfg
+        with ops.stream(sample.stream):
+            if sample.consumed_valid:
+                ops.wait_event(sample.consumed)  # do not overwrite buffers a running iteration still reads
+            if self.dev_sampler is not None:
+                ne, nv, weight = self.dev_sampler(cfg.strategy, sample.dev_edges, sample.dev_nodes)
+            else:
+                edges, nodes, weight, sample.seed = self.dataset.sample(cfg.mini_batch_size, cfg.strategy,
+                                                                        sample.seed)
+                if nodes.size == 0:
+                    raise AmmsbError("mini-batch size = 0!")  # learner.cc:179
+                ne, nv = edges.size, nodes.size
+                if ne > sample.max_edges or nv > sample.max_nodes:
+                    raise AmmsbError("%d | %d" % (ne, sample.max_edges))  # learner.cc:184-188
+                sample.edges, sample.nodes_vec = edges, nodes
+                sample.pin_edges[:ne].copy_(torch.from_numpy(edges.view(np.int64)))
+                sample.pin_nodes[:nv].copy_(torch.from_numpy(nodes.view(np.int32)))
+                sample.dev_edges[:ne].copy_(sample.pin_edges[:ne], non_blocking=True)
+                sample.dev_nodes[:nv].copy_(sample.pin_nodes[:nv], non_blocking=True)
+            sample.n_edges, sample.n_nodes = int(ne), int(nv)
+            sample.neighbor_sampler(sample.n_nodes, sample.dev_nodes)
+            ops.record_event(sample.ready)
+        return weight
+
+    def _launch_sample(self, idx):
+        s = self.samples[idx]
+        if self.pool is not None and self.cfg.sample_parallel:
+            self.futures[idx] = self.pool.submit(self._do_sample, s)
+        else:
+            w = self._do_sample(s)
+            f = concurrent.futures.Future()
+            f.set_result(w)
+            self.futures[idx] = f
+
+    # ------------------------------------------------------------------ multi-GPU exchange
+
+    def _dist(self):
+        import torch.distributed as dist
+        return dist
+
+    def _group_range(self, n_nodes):
+        G = min(n_nodes, MAX_GROUPS)
+        lo = min(self.rank * self.chunk, G)
+        hi = min((self.rank + 1) * self.chunk, G)
+        return G, lo, hi
+
+    def _exchange_phi_vec(self, n_nodes):
+        if self.world == 1:
+            return
+        dist = self._dist()
+        pv = self.phiUpdater.phi_vec
+        G = min(n_nodes, MAX_GROUPS)
+        active = (G + self.chunk - 1) // self.chunk  # ranks that own at least one live group
+        if active <= 1:
+            dist.broadcast(pv[:n_nodes], src=0, group=self.group)  # includes the tail rows (all rank 0's)
+            return
+        self.ops.all_gather_rows(dist, pv, self.chunk, self.rank, self.world, self.group)
+        # tail rows i >= G belong to the rank owning group i - G
+        tail = n_nodes - G
+        for r in range(self.world):
+            lo, hi = r * self.chunk, min((r + 1) * self.chunk, tail)
+            if lo < hi:
+                dist.broadcast(pv[G + lo:G + hi], src=r, group=self.group)
+
+    def _edge_range(self, n_edges):
+        per = (n_edges + self.world - 1) // self.world
+        return min(self.rank * per, n_edges), min((self.rank + 1) * per, n_edges)
+
+    def _reduce_grads(self, local):
+        if self.world == 1:
+            return local
+        dist = self._dist()
+        self.ops.all_gather_flat(dist, self.all_grads, local, self.rank, self.world, self.group)
+        total = self.all_grads[0].clone()
+        for r in range(1, self.world):  # fixed rank order
+            total += self.all_grads[r]
+        return total
+
+    # ------------------------------------------------------------------ the loop (learner.cc:214-250)
+
+    def Run(self, max_iters, signaled=None):
+        ops, cfg = self.ops, self.cfg
+        t1 = time.perf_counter()
+        nsamples = len(self.samples)
+        if nsamples == 2 and self.stepCount == 1 and self.futures[self.phase] is None:
+            self._launch_sample(self.phase)
+        it = 0
+        while it < max_iters and not (signaled is not None and signaled()):
+            ts0 = time.perf_counter()
+            if nsamples == 2:
+                weight = self.futures[self.phase].result()
+                self._launch_sample(1 - self.phase)
+            else:
+                self._launch_sample(self.phase)
+                weight = self.futures[self.phase].result()
+            self.samplingTime += time.perf_counter() - ts0
+            s = self.samples[self.phase]
+            ops.wait_event(s.ready)  # main stream waits for the sample's stream
+            n_nodes, n_edges = s.n_nodes, s.n_edges
+
+            # phiUpdater_(nodes, neighbors, n)  -- phi.cc:728-763
+            phi = self.phiUpdater
+            phi.count_calls += 1
+            G, lo, hi = self._group_range(n_nodes)
+            if n_nodes == 0:
+                raise AmmsbError("mini-batch nodes size = 0!")
+            if lo < hi:
+                phi.update_phi(s.dev_nodes, s.neighbor_sampler.GetData(), n_nodes, lo, hi)
+            self._exchange_phi_vec(n_nodes)
+            phi.update_pi(s.dev_nodes, n_nodes)
+
+            # betaUpdater_(edges, n, weight)  -- beta.cc:334-384
+            beta = self.betaUpdater
+            beta.count_calls += 1
+            e_lo, e_hi = self._edge_range(n_edges)
+            local = beta.calculate_grads(s.dev_edges, n_edges, e_lo, e_hi)
+            beta.update_theta(weight, self._reduce_grads(local))
+
+            ops.record_event(s.consumed)
+            s.consumed_valid = True
+            self.edges_done += n_edges
+            if nsamples == 2:
+                self.phase = 1 - self.phase
+            it += 1
+            self.stepCount += 1
+        self.time += time.perf_counter() - t1
+
+    def HeldoutPerplexity(self):
+        t1 = time.perf_counter()
+        calc = self.heldoutPerplexity
+        calc.count_calls += 1
+        H = calc.num_edges
+        per = (H + self.world - 1) // self.world
+        lo, hi = min(self.rank * per, H), min((self.rank + 1) * per, H)
+        sums = calc.partial(lo, hi)
+        if self.world > 1:
+            dist = self._dist()
+            self.ops.all_gather_flat(dist, self.all_sums, sums, self.rank, self.world, self.group)
+            parts = [calc.unpack(self.all_sums[r]) for r in range(self.world)]
+            tot = [sum(p[i] for p in parts) for i in range(4)]
+        else:
+            tot = calc.unpack(sums)
+        ppx = float(np.exp(np.float32(calc.value(*tot))))  # learner.cc:202 std::exp(ppx)
+        self.time += time.perf_counter() - t1
+        return ppx
+
+    def drain(self):
+        """Wait for the pending background sample and all device work (used before timing / teardown)."""
+        for f in self.futures:
+            if f is not None:
+                f.result()
+        self.ops.synchronize()
+
+    def PrintStats(self, out=print):
+        out("TOTAL    : %.6f" % self.time)
+        out("SAMPLING : %.6f (%%%.2f)" % (self.samplingTime, 100 * self.samplingTime / max(self.time, 1e-12)))
+        out("STEPS    : %d, mini-batch edges %d" % (self.stepCount - 1, self.edges_done))
+
+    def close(self):
+        self.drain()
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)

@@ -353,3 +353,95 @@ class PerplexityCalculator:
     def __call__(self):
         self.count_calls += 1  # perplexity.cc:252
         return self.value(*self.unpack(self.partial()))
+
+
+class DeviceMiniBatchSampler:
+    """Device-side replacement for sampleNode + ExtractNodesFromMiniBatch (sample.cc:249-303,
+    learner.cc:162-173).  The coin flip and the choice of u stay on the host (a numpy Generator), so
+    the sizes of the mini-batch are known without reading anything back; the m distinct non-links /
+    the edges of u are produced on the device straight into the caller's edge and node buffers."""
+
+    def __init__(self, ctx, csr_offsets, csr_targets, training_set, heldout_set, mini_batch, seed=(1234, 5678),
+                 host_seed=20260101):
+        self.ctx = ctx
+        self.m = int(mini_batch)
+        self.N, self.E = int(ctx.params.N), int(ctx.params.E)
+        self.training_set, self.heldout_set = training_set, heldout_set
+        off = np.ascontiguousarray(csr_offsets, dtype=np.uint64)
+        self.degree = np.diff(off.astype(np.int64))
+        if not (self.degree > 0).any():
+            raise AmmsbError("training graph has no edges")
+        self.offsets = ctx.from_numpy(off)
+        self.targets = ctx.from_numpy(np.ascontiguousarray(csr_targets, dtype=np.uint32))
+        self.C = int(ctx.lib.ammsb_minibatch_candidates(self.N, self.m))
+        if self.C == 0:
+            raise AmmsbError("device sampling needs N >= 2 * mini_batch (N=%d, m=%d)" % (self.N, self.m))
+        self.rand = Random(ctx, self.C, seed)
+        self.workspace = ctx.empty((int(ctx.lib.ammsb_minibatch_workspace_bytes(self.C)),), torch.uint8)
+        self.count = ctx.zeros((1,), torch.int32)
+        self.host_rng = np.random.default_rng(host_seed)
+
+    def __call__(self, strategy, dev_edges, dev_nodes):
+        """Enqueue one mini-batch; returns (n_edges, n_nodes, weight)."""
+        c = self.ctx
+        link = {"Node": None, "NodeLink": True, "NodeNonLink": False}.get(strategy, "bad")
+        if link == "bad":
+            raise AmmsbError("device sampling implements Node / NodeLink / NodeNonLink only")
+        if link is None:
+            link = bool(self.host_rng.integers(0, 2))  # rand_r(seed) % 2, sample.cc:297
+        if link:
+            while True:  # sampleNodeLink retries until the vertex has an edge (sample.cc:254-263)
+                u = int(self.host_rng.integers(0, self.N))
+                if self.degree[u] > 0:
+                    break
+            n = int(self.degree[u])
+            c.check(c.lib.ammsb_minibatch_link(c.handle, _ptr(self.offsets), _ptr(self.targets), u, n,
+                                               _ptr(dev_edges), _ptr(dev_nodes), _stream()))
+            return n, n + 1, float(np.float32(self.N))
+        u = int(self.host_rng.integers(0, self.N))
+        hs = C.byref(self.heldout_set.desc) if self.heldout_set is not None else None
+        c.check(c.lib.ammsb_minibatch_nonlink(c.handle, _ptr(self.rand.seeds), self.C, u, self.m,
+                                              C.byref(self.training_set.desc), hs, _ptr(self.workspace),
+                                              _ptr(dev_edges), _ptr(dev_nodes), _ptr(self.count), _stream()))
+        return self.m, self.m + 1, float(np.float32(2 * self.E) / np.float32(self.m))  # sample.cc:292
+
+
+# ---- stream / event / collective plumbing used by learner.py (torch is the transport only)
+
+def new_stream(ctx):
+    return torch.cuda.Stream(device=ctx.device)
+
+
+def stream(s):
+    return torch.cuda.stream(s)
+
+
+def new_event():
+    return torch.cuda.Event()
+
+
+def record_event(ev):
+    ev.record(torch.cuda.current_stream())
+
+
+def wait_event(ev):
+    torch.cuda.current_stream().wait_event(ev)
+
+
+def synchronize():
+    torch.cuda.synchronize()
+
+
+def pinned(shape, dtype):
+    return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+
+def all_gather_rows(dist, buf, chunk, rank, world, group):
+    """In-place all-gather of `world` equal row chunks of buf[:world*chunk] (rank r owns chunk r).
+    RCCL's in-place form (send buffer = its own slot of the receive buffer) moves each chunk once."""
+    dist.all_gather_into_tensor(buf[: world * chunk], buf[rank * chunk:(rank + 1) * chunk], group=group)
+
+
+def all_gather_flat(dist, out, local, rank, world, group):
+    """out[r] = rank r's `local` (tiny payloads: [2K] gradient partials, 4 perplexity scalars)."""
+    dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group)

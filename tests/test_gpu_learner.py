@@ -1,0 +1,118 @@
+"""GPU tests of the callers either side of the kernels: device mini-batch sampler, Learner loop."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import __graft_entry__ as ge
+    ge.build()
+    from mcmc_ammsb_gpu_amd import hostlib, learner, ops
+    return ops, hostlib, learner
+
+
+@pytest.fixture(scope="module")
+def small_ds(env):
+    ops, hostlib, learner = env
+    N = 20000
+    edges = hostlib.generate_graph(N, 16, 16, seed=7)
+    return hostlib.Dataset.robust(N, edges, heldout_ratio=0.02, rand_seed=3)
+
+
+def test_device_minibatch_sampler(env, small_ds):
+    import torch
+    ops, hostlib, learner = env
+    ds = small_ds
+    m = 2048
+    p = ops.make_params(ds.N, 32, E=ds.E, num_node_sample=8)
+    ctx = ops.Context(p)
+    ts = ops.DeviceSet(ctx, ds.training.Serialize(), ds.training.BinsPerBucket(), ds.training.PrimeIdx())
+    hs = ops.DeviceSet(ctx, ds.heldout.Serialize(), ds.heldout.BinsPerBucket(), ds.heldout.PrimeIdx())
+    off, tgt = ds.training_csr()
+
+    def make():
+        return ops.DeviceMiniBatchSampler(ctx, off, tgt, ts, hs, m, seed=(1234, 5678), host_seed=99)
+
+    a, b = make(), make()
+    e = ctx.empty((ds.max_edges(m),), torch.int64)
+    v = ctx.empty((ds.max_nodes(m),), torch.int32)
+    e2, v2 = torch.empty_like(e), torch.empty_like(v)
+    saw = set()
+    for it in range(12):
+        ne, nv, w = a("Node", e, v)
+        ne2, nv2, w2 = b("Node", e2, v2)
+        torch.cuda.synchronize()
+        assert (ne, nv, w) == (ne2, nv2, w2)
+        eh = e[:ne].cpu().numpy().view(np.uint64)
+        vh = v[:nv].cpu().numpy().view(np.uint32)
+        assert np.array_equal(eh, e2[:ne].cpu().numpy().view(np.uint64))  # deterministic in (seeds, u)
+        assert np.array_equal(vh, v2[:nv].cpu().numpy().view(np.uint32))
+        u = vh[0]
+        lo, hi = eh >> np.uint64(32), eh & np.uint64(0xFFFFFFFF)
+        assert (lo < hi).all() and np.unique(eh).size == ne
+        assert ((lo == u) | (hi == u)).all()                      # all edges share the end point u
+        other = np.where(lo == u, hi, lo).astype(np.uint32)
+        assert np.array_equal(other, vh[1:]) and np.unique(vh).size == nv  # node list = {u} + distinct v
+        link = ds.training.Has(eh)
+        if link.all():
+            saw.add("link")
+            assert ne == off[u + 1] - off[u] and w == float(ds.N)
+            assert sorted(other.tolist()) == sorted(tgt[off[u]:off[u + 1]].tolist())
+        else:
+            saw.add("non")
+            assert ne == m and nv == m + 1 and not link.any() and not ds.heldout.Has(eh).any()
+            assert w == float(np.float32(2 * ds.E) / np.float32(m))
+            assert int(a.count.cpu()) >= m  # enough distinct candidates survived
+    assert saw == {"link", "non"}
+    # uniformity of the non-link partner (chi-square on 16 buckets over several draws)
+    hist = np.zeros(16)
+    for it in range(8):
+        a("NodeNonLink", e, v)
+        torch.cuda.synchronize()
+        hist += np.bincount(v[1:m + 1].cpu().numpy().view(np.uint32) * 16 // ds.N, minlength=16)
+    exp = hist.sum() / 16
+    assert ((hist - exp) ** 2 / exp).sum() < 60.0
+
+
+@pytest.mark.parametrize("device_sampling", [False, True])
+def test_learner_runs_and_learns(env, small_ds, device_sampling):
+    import torch
+    ops, hostlib, learner = env
+    cfg = learner.Config.from_cli_defaults(K=32, mini_batch_size=512, num_node_sample=16, phi_wg_size=32,
+                                           beta_wg_size=32, ppx_wg_size=32, device_sampling=device_sampling)
+    lrn = learner.Learner(cfg, small_ds)
+    p0 = lrn.HeldoutPerplexity()
+    lrn.Run(300)
+    p1 = lrn.HeldoutPerplexity()
+    lrn.drain()
+    pi = lrn.pi.host()
+    assert np.isfinite(pi).all() and np.allclose(pi.sum(1), 1.0, atol=1e-4)
+    beta = lrn.beta.cpu().numpy()
+    assert np.isfinite(beta).all() and np.allclose(beta[0::2] + beta[1::2], 1.0, atol=1e-6)
+    assert np.isfinite(p0) and np.isfinite(p1) and p1 < p0, (p0, p1)  # the sampler actually learns
+    assert lrn.stepCount == 301 and lrn.phiUpdater.count_calls == 300 and lrn.betaUpdater.count_calls == 300
+    lrn.close()
+
+
+def test_learner_is_deterministic(env, small_ds):
+    # serialize-test.cc:121-132's contract minus the file round trip: same seeds => bit-identical run
+    ops, hostlib, learner = env
+    out = []
+    for _ in range(2):
+        cfg = learner.Config.from_cli_defaults(K=64, mini_batch_size=256, num_node_sample=8, phi_wg_size=64,
+                                               beta_wg_size=64, ppx_wg_size=64)
+        lrn = learner.Learner(cfg, small_ds)
+        lrn.Run(10)
+        a = lrn.HeldoutPerplexity()
+        lrn.Run(10)
+        b = lrn.HeldoutPerplexity()
+        lrn.drain()
+        out.append((a, b, lrn.pi.host().copy(), lrn.theta.cpu().numpy().copy()))
+        lrn.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
