@@ -74,28 +74,28 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   float pa[2][KPT], pb[2][KPT];
   uint64_t key[2] = {0, 0};
   bool have[2] = {false, false};
+  // Loads are unconditional: an exhausted slot re-reads its first edge (results discarded) and a
+  // column beyond K re-reads column K-1 (its products are zeroed), so no load sits behind a branch.
   auto fetch = [&](int b, uint32_t t) {
-    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
-    have[b] = live && t < trips && e < a.edge_end;
-    uint32_t u = 0, v = 0;
-    if (have[b]) {
-      const uint64_t edge = a.edges[e];
-      u = (uint32_t)(edge >> 32);
-      v = (uint32_t)(edge & 0xffffffffu);
-      key[b] = make_edge(u, v);
-    }
+    const uint64_t e_raw = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
+    have[b] = live && t < trips && e_raw < a.edge_end;
+    const uint64_t e = have[b] ? e_raw : a.edge_begin;
+    const uint64_t edge = a.edges[e];
+    const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
+    key[b] = make_edge(u, v);
     const float* ra = rpm_row(a.pi, u);
     const float* rb = rpm_row(a.pi, v);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const uint32_t k = l + j * L;
-      const bool ok = have[b] && k < K;
-      pa[b][j] = ok ? ra[k] : 0.0f;
-      pb[b][j] = ok ? rb[k] : 0.0f;
+      const uint32_t ck = k < K ? k : K - 1;
+      const float xa = ra[ck], xb = rb[ck];
+      pa[b][j] = k < K ? xa : 0.0f;
+      pb[b][j] = xb;
     }
   };
   auto consume = [&](int b) {
-    const bool y = have[b] && set_has(a.set, key[b]);
+    const bool y = set_has(a.set, key[b]);
     float scratch = 0.0f, ppart = 0.0f;
     float probs[KPT];
 #pragma unroll

@@ -136,6 +136,48 @@ __device__ __forceinline__ float rng_gamma(ammsb_seed& s, const ZigTables* t, fl
   return r * v;
 }
 
+// ---------------------------------------------------------------------------- exact division
+// hipcc lowers an IEEE-correct binary32 `x / d` to
+//     d' = div_scale(d), x' = div_scale(x); r0 = rcp(d'); e0 = fma(-d', r0, 1); r = fma(e0, r0, r0);
+//     q0 = x' * r; e1 = fma(-d', q0, x'); q1 = fma(e1, r, q0); e2 = fma(-d', q1, x');
+//     q  = div_fmas(e2, r, q1); result = div_fixup(q, d, x)
+// (11 VALU instructions).  div_scale only rescales when an operand or the quotient is close to the
+// denormal / overflow range, and div_fmas / div_fixup are the identity then, so for operands in the
+// safe zone below the quotient equals the five-instruction tail q0..q with r computed once per
+// divisor.  The phi kernel divides K/L numerators by the same probs_sum and the same K/L
+// denominators across all n neighbours, so hoisting r removes more than half of its VALU work while
+// staying bit-identical; operands outside the safe zone take the plain `/` path.
+//
+// When is the unscaled tail exact?  It needs the two remainders e1, e2 (about |x| * 2^-24) to be
+// exactly representable, i.e. |x| >= 2^-102, a normal reciprocal, and a quotient away from the
+// denormal / overflow range; then div_scale is a no-op too (its triggers: denormal d, 1/d denormal,
+// exponent(x) <= 23, exponent(x) - exponent(d) >= 96, denormal quotient) and both sequences return the
+// one correctly rounded quotient.  The phi kernel establishes this with range checks hoisted as far
+// out as the data allows (ammsb_phi.hip); anything outside takes the plain `/` path.
+
+constexpr float kProbsLo = 0x1p-100f;                       // smallest |numerator| of the fast path
+constexpr float kPsumLo = 0x1p-30f, kPsumHi = 4.0f;         // probs_sum
+constexpr float kDenLo = 0x1p-110f, kDenHi = 0x1p+40f;      // pi_a * phi_sum
+constexpr float kPhiSumLo = 0x1p-20f, kPhiSumHi = 0x1p+40f; // phi_sum
+constexpr float kBetaHi = 1.0f - 0x1p-20f;                  // beta_k in [EPSILON, kBetaHi] bounds tt to [2^-24, 2]
+
+__device__ __forceinline__ bool in_range(float v, float lo, float hi) { return v >= lo && v <= hi; }
+
+__device__ __forceinline__ float refined_rcp(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  return __builtin_fmaf(e0, r0, r0);
+}
+
+// x / d given r = refined_rcp(d); exact for operands in the safe zone
+__device__ __forceinline__ float div_with_rcp(float x, float d, float r) {
+  const float q0 = x * r;
+  const float e1 = __builtin_fmaf(-d, q0, x);
+  const float q1 = __builtin_fmaf(e1, r, q0);
+  const float e2 = __builtin_fmaf(-d, q1, x);
+  return __builtin_fmaf(e2, r, q1);
+}
+
 // ------------------------------------------------------------------------------------ cuckoo
 // Set_HasEdge, mcmc/cuckoo.cc:27-69.  Both 32-byte bins are fetched at once (two independent
 // 2 x 16 B loads each) instead of the reference's dependent second probe.

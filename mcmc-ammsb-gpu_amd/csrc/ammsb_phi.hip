@@ -38,7 +38,10 @@ struct PhiArgs {
   uint32_t noise_on;
 };
 
-template <int L, int KPT, int DEPTH>
+// FULL: K == L * KPT, so no column guard is needed anywhere.  Loads are always unconditional (row
+// and column indices are clamped instead of predicated): a predicated load turns into a branch plus a
+// full vmcnt(0) drain per element, which serialises the row stream.
+template <int L, int KPT, int DEPTH, bool FULL>
 __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiArgs a) {
   using Grp = Group<L>;
   extern __shared__ uint32_t s_nb_all[];  // [PER_BLOCK][n]: neighbour id | link bit << 31
@@ -55,12 +58,22 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
 
   if (a.noise_on) zig_load(&zig);
 
+  // column owned by (lane, j), its clamped form for addressing, and whether it exists
+  auto col = [&](int j) -> uint32_t { return l + j * L; };
+  auto ccol = [&](int j) -> uint32_t {
+    const uint32_t k = l + j * L;
+    return FULL ? k : (k < K ? k : K - 1);
+  };
+  auto has = [&](int j) -> bool { return FULL || (uint32_t)(l + j * L) < K; };
+
   // per-lane constants: f = beta_k - EPSILON for a link, its exact negation for a non-link
   float bf[KPT];
+  bool beta_safe = true;  // every beta_k this lane owns lies in [EPSILON, 1 - 2^-20] (exact-division fast path)
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    const uint32_t k = l + j * L;
-    bf[j] = k < K ? a.beta[2 * k + 1] - EPS : 0.0f;
+    const float b = a.beta[2 * ccol(j) + 1];
+    bf[j] = b - EPS;
+    beta_safe = beta_safe && in_range(b, EPS, kBetaHi);
   }
 
   ammsb_seed rs = {0, 0};
@@ -69,77 +82,107 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
   const uint32_t trips = (a.n_nodes + a.G - 1) / a.G;  // uniform over the block
   int phase = 0;
   for (uint32_t t = 0; t < trips; ++t) {
-    const uint64_t i = (uint64_t)g + (uint64_t)t * a.G;  // node index handled by this group
-    const bool on = live && i < a.n_nodes;
-    const uint32_t node = on ? a.nodes[i] : 0;
+    const uint64_t i_raw = (uint64_t)g + (uint64_t)t * a.G;  // node index handled by this group
+    const bool on = live && i_raw < a.n_nodes;
+    if constexpr (Grp::PER_BLOCK == 1) {
+      if (!on) continue;  // block-uniform: every thread skips the barriers below together
+    }
+    const uint64_t i = on ? i_raw : 0;  // idle sub-wave groups shadow node 0 and store nothing
+    const uint32_t node = a.nodes[i];
 
     // ---- stage neighbour ids and the n link bits (one cuckoo probe per lane)
     __syncthreads();
-    if (on)
-      for (uint32_t q = l; q < n; q += L) {
-        const uint32_t nb = a.neighbors[i * n + q];
-        const bool y = set_has(a.set, make_edge(node, nb));
-        s_nb[q] = nb | (y ? 0x80000000u : 0u);
-      }
+    for (uint32_t q = l; q < n; q += L) {
+      const uint32_t nb = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nb));
+      s_nb[q] = nb | (y ? 0x80000000u : 0u);
+    }
     __syncthreads();
 
-    const float phi_sum = on ? a.phi_sum[node] : 1.0f;
+    const float phi_sum = a.phi_sum[node];
     const float inv_phi_sum = 1.0f / phi_sum;
     const float* row_a = rpm_row(a.pi, node);
-    float pi_a[KPT], grads[KPT];
+    // den[j] = pi_a[j] * phi_sum is the divisor of every neighbour's second division: refine its
+    // reciprocal once per node (see ammsb_dev.h "exact division")
+    float pi_a[KPT], grads[KPT], den[KPT], rden[KPT];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const uint32_t k = l + j * L;
-      pi_a[j] = (on && k < K) ? row_a[k] : 0.0f;
+      const float x = row_a[ccol(j)];
+      pi_a[j] = has(j) ? x : 0.0f;
       grads[j] = 0.0f;
+      den[j] = pi_a[j] * phi_sum;
+      rden[j] = refined_rcp(den[j]);
+      node_safe = node_safe && (in_range(den[j], kDenLo, kDenHi) || !has(j));
     }
 
     float buf[DEPTH][KPT];
     auto load_row = [&](float (&dst)[KPT], uint32_t q) {
-      uint32_t w = on ? (s_nb[q] & 0x7fffffffu) : 0u;  // idle groups never form an out-of-range row
+      uint32_t w = s_nb[q] & 0x7fffffffu;
       if constexpr (L >= 64) w = __builtin_amdgcn_readfirstlane(w);  // uniform per wave: scalar row base
       const float* row = rpm_row(a.pi, w);
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const uint32_t k = l + j * L;
-        dst[j] = (on && k < K) ? row[k] : 0.0f;
-      }
+      for (int j = 0; j < KPT; ++j) dst[j] = row[ccol(j)];
     };
-    auto consume = [&](const float (&pin)[KPT], uint32_t q) {
-      const bool y = (s_nb[q] >> 31) != 0;
+    auto consume = [&](float (&pin)[KPT], uint32_t q) {
+      bool y = (s_nb[q] >> 31) != 0;
+      if constexpr (L >= 64) y = __builtin_amdgcn_readfirstlane((int)y) != 0;  // wave-uniform branch below
       const float e = y ? EPS : 1.0f - EPS;
-      float probs[KPT];
       float partial = 0.0f;
+      float lo = 1.0f;  // smallest |probs| of this lane (columns that exist)
+      // phi.cc:241-253; pin[] is overwritten with probs[].  pin * (EPS - beta) + e == e - pin * (beta - EPS)
+      // bit for bit, so the non-link case subtracts instead of selecting a negated factor.
+      if (y) {
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {  // phi.cc:241-253
-        const float f = y ? bf[j] : -bf[j];
-        float tt = pin[j] * f;
-        tt = tt + e;
-        probs[j] = pi_a[j] * tt;
-        partial += probs[j];
+        for (int j = 0; j < KPT; ++j) {
+          float tt = pin[j] * bf[j];
+          tt = tt + e;
+          pin[j] = pi_a[j] * tt;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+          const float tt0 = pin[j] * bf[j];
+          const float tt = e - tt0;
+          pin[j] = pi_a[j] * tt;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        partial += pin[j];  // 0 for a column beyond K (pi_a = 0)
+        lo = fminf(lo, has(j) ? fabsf(pin[j]) : 1.0f);
       }
       const float probs_sum = Grp::sum(partial, aux, phase);  // phi.cc:254-257
+      // phi.cc:259-263: grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
+      if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+        const float rps = refined_rcp(probs_sum);
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {  // phi.cc:259-263
-        float qv = probs[j] / probs_sum;
-        const float den = pi_a[j] * phi_sum;
-        qv = qv / den;
-        grads[j] += qv - inv_phi_sum;
+        for (int j = 0; j < KPT; ++j) {
+          float qv = div_with_rcp(pin[j], probs_sum, rps);
+          qv = div_with_rcp(qv, den[j], rden[j]);
+          grads[j] += qv - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+          float qv = pin[j] / probs_sum;
+          qv = qv / den[j];
+          grads[j] += qv - inv_phi_sum;
+        }
       }
     };
 
+    // software pipeline, DEPTH-1 rows ahead; the tail re-requests the last row instead of branching
+    const uint32_t last = n - 1;
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
-      if ((uint32_t)d < n) load_row(buf[d], d);
+    for (int d = 0; d < DEPTH - 1; ++d) load_row(buf[d], (uint32_t)d < last ? (uint32_t)d : last);
     for (uint32_t q0 = 0; q0 < n; q0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
         const uint32_t q = q0 + d;
-        if (q < n) {
-          const uint32_t qn = q + DEPTH - 1;
-          if (qn < n) load_row(buf[(d + DEPTH - 1) % DEPTH], qn);
-          consume(buf[d], q);
-        }
+        const uint32_t qn = q + DEPTH - 1;
+        if (qn < n) load_row(buf[(d + DEPTH - 1) % DEPTH], qn);
+        if (q < n) consume(buf[d], q);
       }
     }
 
@@ -149,8 +192,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
       const float half = a.eps_t / 2;
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {
-        const uint32_t k = l + j * L;
-        if (k < K) {
+        if (has(j)) {
           const float noise = a.noise_on ? rng_normal(rs, &zig) : 1.0f;
           const float phi_k = pi_a[j] * phi_sum;
           const float ng = a.Nn * grads[j];
@@ -162,7 +204,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
           const float sq = sqrtf(ep);
           const float bb = sq * noise;
           const float v = fabsf(aa + bb);
-          out[k] = v > 1e-24f ? v : 1e-24f;
+          out[col(j)] = v > 1e-24f ? v : 1e-24f;
         }
       }
     }
@@ -206,10 +248,13 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_pi_kernel(ammsb_rpm pi
 template <int L, int KPT>
 int launch_phi(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   using Grp = Group<L>;
-  constexpr int DEPTH = KPT >= 32 ? 2 : (KPT >= 16 ? 3 : 4);
+  constexpr int DEPTH = KPT >= 32 ? 2 : 4;
   const uint32_t blocks = (n_groups + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
   const size_t lds = sizeof(uint32_t) * Grp::PER_BLOCK * a.n;
-  update_phi_kernel<L, KPT, DEPTH><<<blocks, Grp::BLOCK, lds, s>>>(a);
+  if (a.K == (uint32_t)(L * KPT))
+    update_phi_kernel<L, KPT, DEPTH, true><<<blocks, Grp::BLOCK, lds, s>>>(a);
+  else
+    update_phi_kernel<L, KPT, DEPTH, false><<<blocks, Grp::BLOCK, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

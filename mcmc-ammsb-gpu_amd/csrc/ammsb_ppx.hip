@@ -55,28 +55,27 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void ppx_kernel(const PpxArgs a) {
   float pa[2][KPT], pb[2][KPT];
   uint64_t key[2] = {0, 0}, pos[2] = {0, 0};
   bool have[2] = {false, false};
+  // unconditional loads: exhausted slots shadow their first edge, columns beyond K shadow column K-1
   auto fetch = [&](int b, uint32_t t) {
-    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
-    have[b] = live && t < trips && e < a.edge_end;
-    uint32_t u = 0, v = 0;
-    if (have[b]) {
-      pos[b] = e;
-      key[b] = a.edges[e];  // used as stored: no canonicalisation (perplexity.cc:45-47)
-      u = (uint32_t)(key[b] >> 32);
-      v = (uint32_t)(key[b] & 0xffffffffu);
-    }
+    const uint64_t e_raw = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
+    have[b] = live && t < trips && e_raw < a.edge_end;
+    const uint64_t e = have[b] ? e_raw : a.edge_begin;
+    pos[b] = e;
+    key[b] = a.edges[e];  // used as stored: no canonicalisation (perplexity.cc:45-47)
+    const uint32_t u = (uint32_t)(key[b] >> 32), v = (uint32_t)(key[b] & 0xffffffffu);
     const float* ra = rpm_row(a.pi, u);
     const float* rb = rpm_row(a.pi, v);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const uint32_t k = l + j * L;
-      const bool ok = have[b] && k < K;
-      pa[b][j] = ok ? ra[k] : 0.0f;
-      pb[b][j] = ok ? rb[k] : 0.0f;
+      const uint32_t ck = k < K ? k : K - 1;
+      const float xa = ra[ck], xb = rb[ck];
+      pa[b][j] = k < K ? xa : 0.0f;
+      pb[b][j] = xb;
     }
   };
   auto consume = [&](int b) {
-    const bool y = have[b] && set_has(a.set, key[b]);
+    const bool y = set_has(a.set, key[b]);
     float s_part = 0.0f, f_part = 0.0f;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {  // perplexity.cc:100-119

@@ -301,6 +301,50 @@ def test_update_phi_and_pi(orc, hip, N, K, n, n_nodes, L, noise):
     assert np.allclose(pr.pi.host()[pr.nodes_h].sum(1), 1.0, atol=2e-6)
 
 
+@pytest.mark.parametrize("case", ["floor_pi", "beta_edges", "tiny_phi_sum", "mixed"])
+@pytest.mark.parametrize("L,K", [(64, 1024), (128, 512), (32, 96)])
+def test_update_phi_extreme_values(orc, hip, case, L, K):
+    """The kernel replaces `x / d` by a hoisted-reciprocal form only inside a proven-safe operand range
+    (ammsb_dev.h "exact division"); these inputs sit on and beyond every edge of that range -- pi
+    entries at the 1e-24 clamp floor (what a trained model looks like), beta within 1e-8 of 0 and 1,
+    tiny and huge phi_sum -- and must still match the IEEE oracle bit for bit."""
+    import torch
+    N, n, n_nodes = 1024, 16, 96
+    pr = Problem(orc, hip, N, K, n, n_nodes, link_frac=0.5)
+    rng = np.random.default_rng(17)
+    if case in ("floor_pi", "mixed"):
+        mask = rng.random((N, K)) < 0.7                      # most memberships at the clamp floor
+        phi = pr.pi_h * pr.phi_sum_h[:, None]
+        phi[mask] = np.float32(1e-24)
+        phi[rng.random((N, K)) < 0.01] = np.float32(3e-39)   # denormal-sized entries
+        pr.phi_sum_h[:] = phi.sum(1, dtype=np.float32)
+        pr.pi_h[:] = phi / pr.phi_sum_h[:, None]
+    if case in ("beta_edges", "mixed"):
+        b = pr.beta_h.reshape(-1, 2)
+        k = np.arange(K)
+        b[k % 7 == 0, 1] = np.float32(1.0) - np.float32(6e-8)
+        b[k % 7 == 1, 1] = np.float32(5e-8)                  # below EPSILON: beta - EPSILON < 0
+        b[k % 7 == 2, 1] = np.float32(1e-7)
+        b[:, 0] = np.float32(1.0) - b[:, 1]
+        pr.beta.copy_(pr.ctx.from_numpy(pr.beta_h))
+    if case in ("tiny_phi_sum", "mixed"):
+        pr.phi_sum_h[::3] *= np.float32(1e-9)
+        pr.phi_sum_h[1::3] *= np.float32(1e9)
+    pr.pi.load(pr.pi_h)
+    pr.phi_sum.copy_(pr.ctx.from_numpy(pr.phi_sum_h))
+    upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L)
+    seeds = orc.rng_init(n_nodes * L, 42, 43)
+    upd.count_calls = 1
+    upd.update_phi(pr.nodes, pr.nb, n_nodes)
+    pr.sync()
+    want = orc.update_phi(pr.p_orc, pr.beta_h, pr.pi_h.reshape(-1), pr.phi_sum_h, pr.oset, pr.nodes_h,
+                          pr.nb_h.reshape(-1), 1, seeds, L, 1, True)
+    got = upd.phi_vec.cpu().numpy()[:n_nodes]
+    same = got.view(np.uint32) == want.view(np.uint32)
+    both_nan = np.isnan(got) & np.isnan(want)
+    assert (same | both_nan).all(), "mismatch at %s" % (np.argwhere(~(same | both_nan))[:5],)
+
+
 def test_update_phi_more_nodes_than_groups(orc, hip):
     # n_nodes > 65535: groups 0.. handle two nodes each and carry their stream state (phi.cc:292-300)
     N, K, n, L = 70000, 32, 4, 32
