@@ -229,12 +229,32 @@ struct Group {
   __device__ __forceinline__ static int lane() { return threadIdx.x & (L - 1); }
   __device__ __forceinline__ static int slot() { return threadIdx.x / L; }
 
+  // Full-wave float form without LDS traffic: v_permlane32_swap / v_permlane16_swap (gfx950) fold
+  // lanes l+32 and l+16 onto l, four DPP row_shl adds fold l+8, l+4, l+2, l+1 -- at every step lane l
+  // (l < p2) computes aux[l] + aux[l+p2], the reference tree -- and lane 0 is broadcast through an SGPR.
+  __device__ __forceinline__ static float wave_tree64(float v) {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));  // row_shl:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));  // row_shl:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));  // row_shl:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));  // row_shl:1
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+  }
+
   template <typename T>
   __device__ __forceinline__ static T wave_tree(T v) {
     constexpr int W = L < 64 ? L : 64;
+    if constexpr (W == 64 && sizeof(T) == 4 && __is_same(T, float)) {
+      return wave_tree64(v);
+    } else {
 #pragma unroll
-    for (int p2 = W >> 1; p2 > 0; p2 >>= 1) v += __shfl_xor(v, p2, 64);
-    return v;
+      for (int p2 = W >> 1; p2 > 0; p2 >>= 1) v += __shfl_xor(v, p2, 64);
+      return v;
+    }
   }
 
   // `phase` alternates 0/1 between consecutive calls so that one barrier per call suffices.

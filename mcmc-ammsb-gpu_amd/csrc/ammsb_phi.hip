@@ -16,6 +16,8 @@
 // (one latency instead of n dependent ones, as the reference's lane-0-style lookup would cost).
 #pragma clang fp contract(off)
 
+#include <stdlib.h>
+
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
 
@@ -104,16 +106,16 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
     const float* row_a = rpm_row(a.pi, node);
     // den[j] = pi_a[j] * phi_sum is the divisor of every neighbour's second division: refine its
     // reciprocal once per node (see ammsb_dev.h "exact division")
-    float pi_a[KPT], grads[KPT], den[KPT], rden[KPT];
+    float pi_a[KPT], grads[KPT], rden[KPT];  // den itself is recomputed where needed (one multiply)
     bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const float x = row_a[ccol(j)];
       pi_a[j] = has(j) ? x : 0.0f;
       grads[j] = 0.0f;
-      den[j] = pi_a[j] * phi_sum;
-      rden[j] = refined_rcp(den[j]);
-      node_safe = node_safe && (in_range(den[j], kDenLo, kDenHi) || !has(j));
+      const float den = pi_a[j] * phi_sum;
+      rden[j] = refined_rcp(den);
+      node_safe = node_safe && (in_range(den, kDenLo, kDenHi) || !has(j));
     }
 
     float buf[DEPTH][KPT];
@@ -159,31 +161,44 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
           float qv = div_with_rcp(pin[j], probs_sum, rps);
-          qv = div_with_rcp(qv, den[j], rden[j]);
+          qv = div_with_rcp(qv, pi_a[j] * phi_sum, rden[j]);
           grads[j] += qv - inv_phi_sum;
         }
       } else {
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
           float qv = pin[j] / probs_sum;
-          qv = qv / den[j];
+          qv = qv / (pi_a[j] * phi_sum);
           grads[j] += qv - inv_phi_sum;
         }
       }
     };
 
-    // software pipeline, DEPTH-1 rows ahead; the tail re-requests the last row instead of branching
-    const uint32_t last = n - 1;
+    // Software pipeline, DEPTH-1 rows ahead.  The steady state is straight-line code (no branch around
+    // a load): hipcc's wait-count insertion falls back to vmcnt(0) -- draining the rows just requested
+    // -- when paths with different numbers of outstanding loads meet.  n = G*DEPTH + r rows: the first
+    // G-1 groups request and consume DEPTH rows each, the last group requests only its last row, the r
+    // left-over rows are handled one at a time.
+    const uint32_t groups = n / DEPTH;
+    if (groups > 0) {
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) load_row(buf[d], (uint32_t)d < last ? (uint32_t)d : last);
-    for (uint32_t q0 = 0; q0 < n; q0 += DEPTH) {
+      for (int d = 0; d < DEPTH - 1; ++d) load_row(buf[d], d);
+      for (uint32_t gq = 0; gq + 1 < groups; ++gq) {
+        const uint32_t q0 = gq * DEPTH;
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        const uint32_t q = q0 + d;
-        const uint32_t qn = q + DEPTH - 1;
-        if (qn < n) load_row(buf[(d + DEPTH - 1) % DEPTH], qn);
-        if (q < n) consume(buf[d], q);
+        for (int d = 0; d < DEPTH; ++d) {
+          load_row(buf[(d + DEPTH - 1) % DEPTH], q0 + d + DEPTH - 1);
+          consume(buf[d], q0 + d);
+        }
       }
+      const uint32_t q0 = (groups - 1) * DEPTH;
+      load_row(buf[DEPTH - 1], q0 + DEPTH - 1);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) consume(buf[d], q0 + d);
+    }
+    for (uint32_t q = groups * DEPTH; q < n; ++q) {
+      load_row(buf[0], q);
+      consume(buf[0], q);
     }
 
     // ---- SGLD step, phi.cc:265-274; lane l draws for k = l, l+L, ... in ascending order
@@ -210,6 +225,166 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
     }
   }
   if (live && a.noise_on) a.seeds[(uint64_t)g * L + l] = rs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-streamed form of update_phi for L = 64 and K = 64 * KPT (KPT in {4, 8, 16, 32}).
+//
+// The register-pipelined kernel above keeps DEPTH neighbour rows per wave in VGPRs; with the
+// persistent per-column state that costs ~250 VGPRs at K = 1024, i.e. two waves per SIMD, and a wave
+// that is computing cannot cover its partner's memory stalls: measured VALU busy 45 %, HBM 51 %.
+// Here neighbour rows never enter VGPRs wholesale: each wave owns a two-slot LDS ring that is filled
+// by LDS-DMA (global_load_lds_dwordx4: 4 x 1 KiB pieces per 4 KiB row, per-lane source address,
+// wave-uniform LDS destination) one row ahead, reads a row with ds_read2st64_b32 (lane l gets columns
+// l + 64 j -- the reference's lane ownership, hence its WG_SUM order), writes probs[] back in place
+// and re-reads it for the gradient pass.  ~100 VGPRs -> 4 waves per SIMD, 16 rows in flight per CU.
+// Arithmetic, operation order and RNG consumption are those of the register kernel, bit for bit.
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int KPT>
+__global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
+  using Grp = Group<64>;
+  constexpr int K = 64 * KPT;
+  constexpr int PIECES = KPT / 4;  // 1 KiB LDS-DMA pieces per row
+  extern __shared__ __align__(16) char smem[];  // [2][K] floats (ring) then [n] u32 (neighbour id | link bit)
+  __shared__ ZigTables zig;
+  float* ring = reinterpret_cast<float*>(smem);
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + 2 * K * sizeof(float));
+
+  const int l = threadIdx.x;
+  const uint32_t g = a.group_begin + blockIdx.x;
+  if (g >= a.group_end) return;  // block-uniform
+  const uint32_t n = a.n;
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  float bf[KPT];
+  bool beta_safe = true;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const float b = a.beta[2 * (l + 64 * j) + 1];
+    bf[j] = b - EPS;
+    beta_safe = beta_safe && in_range(b, EPS, kBetaHi);
+  }
+  ammsb_seed rs = {0, 0};
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * 64 + l];
+
+  // request neighbour row q into ring slot `slot`
+  auto request = [&](uint32_t q, uint32_t slot) {
+    const uint32_t w = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
+    const float* src = rpm_row(a.pi, w) + 4 * l;
+    char* dst = smem + slot * (K * sizeof(float));
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 256 * p), (lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+  };
+
+  int phase = 0;
+  for (uint64_t i = g; i < a.n_nodes; i += a.G) {
+    const uint32_t node = a.nodes[i];
+    __syncthreads();  // single-wave block: orders the LDS traffic of consecutive nodes
+    for (uint32_t q = l; q < n; q += 64) {
+      const uint32_t nb = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nb));
+      s_nb[q] = nb | (y ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+
+    const float phi_sum = a.phi_sum[node];
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = rpm_row(a.pi, node);
+    float pi_a[KPT], grads[KPT], rden[KPT];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) pi_a[j] = row_a[l + 64 * j];
+    request(0, 0);  // the first row's flight overlaps the per-node set-up below
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      grads[j] = 0.0f;
+      const float den = pi_a[j] * phi_sum;
+      rden[j] = refined_rcp(den);
+      node_safe = node_safe && in_range(den, kDenLo, kDenHi);
+    }
+
+    for (uint32_t q = 0; q < n; ++q) {
+      const uint32_t slot = q & 1;
+      float* row = ring + slot * K;
+      // every LDS read of the other slot (row q-1) has been consumed; refill it with row q+1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (q + 1 < n) {
+        request(q + 1, slot ^ 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // row q landed, row q+1 in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bool y = (s_nb[q] >> 31) != 0;
+      y = __builtin_amdgcn_readfirstlane((int)y) != 0;
+      const float e = y ? EPS : 1.0f - EPS;
+
+      // pass 1 (phi.cc:241-253): probs[] in place of the row, lane partial in ascending column order
+      float partial = 0.0f, lo = 1.0f;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const float tt0 = row[l + 64 * j] * bf[j];
+        const float tt = y ? tt0 + e : e - tt0;  // pin * (EPS - beta) + e == e - pin * (beta - EPS), bit for bit
+        const float pr = pi_a[j] * tt;
+        row[l + 64 * j] = pr;
+        partial += pr;
+        lo = fminf(lo, fabsf(pr));
+      }
+      const float probs_sum = Grp::sum(partial, (float*)nullptr, phase);  // phi.cc:254-257
+
+      // pass 2 (phi.cc:259-263): grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
+      if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+        const float rps = refined_rcp(probs_sum);
+        float ps = phi_sum;
+        asm volatile("" : "+v"(ps));  // keeps pi_a * phi_sum from being hoisted into KPT more registers
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+          float qv = div_with_rcp(row[l + 64 * j], probs_sum, rps);
+          qv = div_with_rcp(qv, pi_a[j] * ps, rden[j]);
+          grads[j] += qv - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+          float qv = row[l + 64 * j] / probs_sum;
+          qv = qv / (pi_a[j] * phi_sum);
+          grads[j] += qv - inv_phi_sum;
+        }
+      }
+    }
+
+    // SGLD step, phi.cc:265-274
+    float* out = a.phi_vec + i * K;
+    const float half = a.eps_t / 2;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const float noise = a.noise_on ? rng_normal(rs, &zig) : 1.0f;
+      const float phi_k = pi_a[j] * phi_sum;
+      const float ng = a.Nn * grads[j];
+      float in = a.alpha - phi_k;
+      in = in + ng;
+      const float drift = half * in;
+      const float aa = phi_k + drift;
+      const float ep = a.eps_t * phi_k;
+      const float sq = sqrtf(ep);
+      const float bb = sq * noise;
+      const float v = fabsf(aa + bb);
+      out[l + 64 * j] = v > 1e-24f ? v : 1e-24f;
+    }
+  }
+  if (a.noise_on) a.seeds[(uint64_t)g * 64 + l] = rs;
+}
+
+template <int KPT>
+int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = 2 * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  update_phi_lds_kernel<KPT><<<n_groups, 64, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
 }
 
 // update_pi, phi.cc:177-197: copy phi_vec row into pi, WG_NORMALIZE it, phi_sum[node] = sum.
@@ -346,6 +521,18 @@ extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_r
   if (a.group_begin >= a.group_end) return AMMSB_OK;
   const uint32_t n_groups = a.group_end - a.group_begin;
   hipStream_t s = as_stream(stream);
+  static const bool force_reg = [] {
+    const char* f = getenv("AMMSB_PHI_FORM");
+    return f && f[0] == 'r';
+  }();
+  if (wg == 64 && !force_reg && p.K == 64ull * kpt && kpt >= 4 && pi->num_cols % 4 == 0) {
+    switch (kpt) {
+      case 4: return launch_phi_lds<4>(ctx, a, n_groups, s);
+      case 8: return launch_phi_lds<8>(ctx, a, n_groups, s);
+      case 16: return launch_phi_lds<16>(ctx, a, n_groups, s);
+      case 32: return launch_phi_lds<32>(ctx, a, n_groups, s);
+    }
+  }
   AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, return (launch_phi<L_, KPT_>(ctx, a, n_groups, s))));
   return AMMSB_OK;
 }
