@@ -75,7 +75,8 @@ def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
     import ctypes as C
     cores = L.orc_num_threads()
     K, n = cfg.K, cfg.num_node_sample
-    s = args.cpu_sample or max(256, min(4096, (24 * cores * 64) // max(K // 64, 1)))
+    # ~12 ms of one core per (node, edge) pair at K=1024, n=32: aim at roughly 10 s of wall time
+    s = args.cpu_sample or max(256, int(800 * cores * 1024 / max(K, 32)))
     s = min(s, n_nodes_big - 1)
     rng = np.random.default_rng(1)
     p = orc.make_params(cfg.N, K, n, alpha=np.float32(cfg.alpha))
