@@ -213,13 +213,15 @@ class Learner:
         if active <= 1:
             dist.broadcast(pv[:n_nodes], src=0, group=self.group)  # includes the tail rows (all rank 0's)
             return
-        self.ops.all_gather_rows(dist, pv, self.chunk, self.rank, self.world, self.group)
-        # tail rows i >= G belong to the rank owning group i - G
+        # Tail rows i >= G belong to the rank owning group i - G.  They are broadcast FIRST: a tail row
+        # can lie inside another rank's all-gather chunk (row 65535 sits in the last chunk), and the
+        # in-place all-gather below would otherwise overwrite the owner's value with a stale one.
         tail = n_nodes - G
         for r in range(self.world):
             lo, hi = r * self.chunk, min((r + 1) * self.chunk, tail)
             if lo < hi:
                 dist.broadcast(pv[G + lo:G + hi], src=r, group=self.group)
+        self.ops.all_gather_rows(dist, pv, self.chunk, self.rank, self.world, self.group)
 
     def _edge_range(self, n_edges):
         per = (n_edges + self.world - 1) // self.world

@@ -1,0 +1,105 @@
+"""N > 1 path on CPU: world size 2, gloo backend.  The product's learner.py (sharding by virtual-group
+range / edge range, phi_vec all-gather + tail broadcasts, rank-ordered gradient sum, perplexity scalar
+gather) runs unchanged; only the operator set is swapped for the oracle-backed one in
+tests/oracle_ops.py, so the collective logic is what is under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, outdir, case):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    import oracle_lib
+    oracle_lib.lib().orc_set_num_threads(2)
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib, learner
+    import oracle_ops
+    group = None
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    N, K, m, n, iters = case
+    edges = hostlib.generate_graph(N, 8, 12, seed=5)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
+    cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=32, beta_wg_size=32,
+                                           ppx_wg_size=32, strategy="Node", sample_parallel=True)
+    lrn = learner.Learner(cfg, ds, ops=oracle_ops, rank=rank, world_size=world, group=group)
+    p0 = lrn.HeldoutPerplexity()
+    lrn.Run(1)
+    pi1 = lrn.pi.host()
+    lrn.Run(iters - 1)
+    p1 = lrn.HeldoutPerplexity()
+    lrn.drain()
+    np.savez(os.path.join(outdir, "w%d_r%d.npz" % (world, rank)), pi1=pi1, pi=lrn.pi.host(), phi=lrn.phi.numpy(),
+             theta=lrn.theta.numpy(), beta=lrn.beta.numpy(), ppx=np.array([p0, p1]), edges=np.array([lrn.edges_done]),
+             seeds=lrn.phiUpdater.rand.host().view(np.uint64), ppx_state=lrn.heldoutPerplexity.ppx_per_edge.numpy())
+    lrn.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [
+    (3000, 32, 256, 8, 6),        # link + non-link batches, everything owned by rank 0's group range or split
+    (150000, 32, 70000, 2, 2),    # > 65535 mini-batch nodes: both ranks own groups, tail rows beyond group 65534
+], ids=["small", "tail"])
+def test_world2_matches_single_process(tmp_path, case):
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    out = str(tmp_path)
+    _run(0, 1, 0, out, case)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    r0 = np.load(os.path.join(out, "w2_r0.npz"))
+    r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    # replicas stay identical
+    for k in ("pi", "phi", "theta", "beta", "ppx", "edges"):
+        assert np.array_equal(r0[k], r1[k]), k
+    # first iteration: phi/pi do not depend on how groups are split over ranks -> bit-identical to 1 process
+    assert np.array_equal(r0["pi1"], one["pi1"])
+    assert r0["edges"][0] == one["edges"][0]
+    assert r0["ppx"][0] == one["ppx"][0]
+    # later iterations see beta from a gradient summed in a different association (slices, rank order)
+    assert np.allclose(r0["theta"], one["theta"], rtol=2e-5, atol=1e-7)
+    assert np.allclose(r0["pi"], one["pi"], rtol=5e-4, atol=1e-7)
+    assert abs(r0["ppx"][1] - one["ppx"][1]) <= 1e-5 * one["ppx"][1]
+    # stream ownership is fixed: the union of the two ranks' advanced streams equals the single-process state
+    chunk = (65535 + 1) // 2
+    L = 32
+    s0, s1, s = r0["seeds"].reshape(-1, 2), r1["seeds"].reshape(-1, 2), one["seeds"].reshape(-1, 2)
+    lim = min(s.shape[0], chunk * L)
+    assert np.array_equal(s0[:lim], s[:lim])
+    if s.shape[0] > chunk * L:
+        assert np.array_equal(s1[chunk * L:], s[chunk * L:])
+    # perplexity state: each rank owns a contiguous slice of the held-out edges
+    H = one["ppx_state"].size
+    per = (H + 1) // 2
+    assert np.allclose(r0["ppx_state"][:per], one["ppx_state"][:per], rtol=1e-4)
+    assert np.allclose(r1["ppx_state"][per:], one["ppx_state"][per:], rtol=1e-4)
