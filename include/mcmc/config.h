@@ -66,6 +66,10 @@ struct Config {
 
   // new: draw mini-batches on the device instead of with the host samplers above
   bool device_sampling;
+  // new: rand_r seeds of the two Sample buffers.  The reference takes them from the process-global
+  // rand() (sample.cc:132), which is not reproducible once the HIP runtime shares the process (its
+  // start-up consumes rand() too); the defaults are what rand() returns first after srand(1).
+  unsigned int sample_seed[2];
 
   Config();
 };

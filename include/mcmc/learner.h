@@ -1,0 +1,60 @@
+// mcmc::Learner: drop-in for the reference's mcmc/learner.h:18-88 (same constructor, same methods).
+#ifndef MCMC_AMD_LEARNER_H_
+#define MCMC_AMD_LEARNER_H_
+
+#include <signal.h>
+
+#include <future>
+#include <memory>
+#include <ostream>
+
+#include "mcmc/config.h"
+#include "mcmc/data.h"
+#include "mcmc/operators.h"
+
+namespace mcmc {
+
+class Learner {
+ public:
+  Learner(const Config& cfg, clcuda::Queue queue);
+  ~Learner();
+
+  void Run(uint32_t max_iters, sig_atomic_t* signaled = nullptr);  // learner.cc:214-250
+  Float HeldoutPerplexity();                                       // learner.cc:196-203
+  void PrintStats(std::ostream& out);                              // learner.cc:252-299
+  void PrintStats();
+
+  // read-back helpers for tests / drivers (not in the reference API)
+  std::vector<Float> GetBeta();
+  std::vector<Float> GetTheta();
+  std::vector<Float> GetPiRow(Vertex v);
+  uint64_t MiniBatchEdges() const { return edges_done_; }
+
+ private:
+  Float DoSample(Sample* sample);  // learner.cc:175-194
+
+  const Config& cfg_;
+  clcuda::Queue queue_;
+  clcuda::Buffer<Float> beta_;
+  clcuda::Buffer<Float> theta_;
+  std::shared_ptr<RowPartitionedMatrixFactory<Float>> allocFactory_;
+  std::unique_ptr<RowPartitionedMatrix<Float>> pi_;
+  clcuda::Buffer<Float> phi_;
+  std::shared_ptr<OpenClSetFactory> setFactory_;
+  std::unique_ptr<OpenClSet> trainingSet_;
+  std::unique_ptr<OpenClSet> heldoutSet_;
+  clcuda::Buffer<Edge> heldoutEdges_;
+  PerplexityCalculator heldoutPerplexity_;
+  PhiUpdater phiUpdater_;
+  BetaUpdater betaUpdater_;
+  SamplerFn sampler_;
+  uint32_t stepCount_;
+  uint64_t time_, samplingTime_, edges_done_;
+  std::unique_ptr<Sample> samples_[2];  // MCMC_SAMPLE_PARALLEL (CMakeLists.txt:42, default ON)
+  std::future<Float> futures_[2];
+  int phase_;
+};
+
+}  // namespace mcmc
+
+#endif  // MCMC_AMD_LEARNER_H_

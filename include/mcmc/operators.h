@@ -1,0 +1,220 @@
+// Device-side operators with the reference's class names and call signatures:
+//   RowPartitionedMatrix<Float> / Factory   mcmc/partitioned-alloc.h:73-187
+//   OpenClSet / OpenClSetFactory            mcmc/cuckoo.h:69-105   (device image of a cuckoo Set)
+//   random::OpenClRandom / Factory          mcmc/random.h:22-62
+//   random::RandomAndNormalize, RandomGammaAndNormalize  mcmc/random.h:64-79
+//   NeighborSampler, Sample                 mcmc/sample.h:16-92
+//   PhiUpdater                              mcmc/phi.h:10-61
+//   BetaUpdater                             mcmc/beta.h:15-72
+//   PerplexityCalculator                    mcmc/perplexity.h:23-114
+// Each forwards to one C-ABI call of include/ammsb.h.  The compileFlags / baseFuncs constructor
+// arguments of the reference (JIT inputs) are accepted and ignored.  Fatal conditions throw
+// std::runtime_error with the reference's message where it LOG(FATAL)s.
+#ifndef MCMC_AMD_OPERATORS_H_
+#define MCMC_AMD_OPERATORS_H_
+
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ammsb.h"
+#include "mcmc/config.h"
+#include "mcmc/device.h"
+
+namespace mcmc {
+
+// One ammsb context per (device, Config constants); shared by the operators built from one Config.
+std::shared_ptr<ammsb_ctx> AcquireContext(const Config& cfg, const clcuda::Queue& queue);
+void ThrowIfError(ammsb_ctx* ctx, int rc, const char* what);
+
+template <class T>
+class RowPartitionedMatrix {
+ public:
+  RowPartitionedMatrix(clcuda::Queue queue, uint32_t rows, uint32_t cols, uint32_t rows_in_block = 0);
+  uint32_t Rows() const { return rows_; }
+  uint32_t Cols() const { return cols_; }
+  uint32_t RowsPerBlock() const { return rows_per_alloc_; }
+  std::vector<clcuda::Buffer<T>>& Blocks() { return blocks_; }
+  const ammsb_rpm& Get() const { return desc_; }
+
+ private:
+  clcuda::Queue queue_;
+  uint32_t rows_, cols_, rows_per_alloc_;
+  std::vector<clcuda::Buffer<T>> blocks_;
+  ammsb_rpm desc_;
+};
+
+template <class T>
+class RowPartitionedMatrixFactory {
+ public:
+  static std::shared_ptr<RowPartitionedMatrixFactory> New(clcuda::Queue queue) {
+    return std::shared_ptr<RowPartitionedMatrixFactory>(new RowPartitionedMatrixFactory(queue));
+  }
+  RowPartitionedMatrix<T>* CreateMatrix(uint32_t rows, uint32_t cols, uint32_t rows_in_block = 0) {
+    return new RowPartitionedMatrix<T>(queue_, rows, cols, rows_in_block);
+  }
+
+ private:
+  explicit RowPartitionedMatrixFactory(clcuda::Queue queue) : queue_(queue) {}
+  clcuda::Queue queue_;
+};
+
+class OpenClSet {
+ public:
+  OpenClSet(clcuda::Queue queue, const Set& set);
+  const ammsb_set& Get() const { return desc_; }
+
+ private:
+  clcuda::Buffer<Edge> data_;
+  ammsb_set desc_;
+};
+
+class OpenClSetFactory {
+ public:
+  static std::shared_ptr<OpenClSetFactory> New(clcuda::Queue queue) {
+    return std::shared_ptr<OpenClSetFactory>(new OpenClSetFactory(queue));
+  }
+  OpenClSet* CreateSet(const Set& set) { return new OpenClSet(queue_, set); }
+
+ private:
+  explicit OpenClSetFactory(clcuda::Queue queue) : queue_(queue) {}
+  clcuda::Queue queue_;
+};
+
+namespace random {
+
+typedef ::mcmc::ulong2 random_seed_t;
+
+class OpenClRandom {
+ public:
+  OpenClRandom(clcuda::Queue queue, uint64_t size, random_seed_t seed);
+  void SetSeed(random_seed_t seed);
+  clcuda::Buffer<ammsb_seed>& GetSeeds() { return data_; }
+  ammsb_seed* Get() { return data_.data(); }
+
+ private:
+  clcuda::Queue queue_;
+  clcuda::Buffer<ammsb_seed> data_;
+};
+
+class OpenClRandomFactory {
+ public:
+  static std::shared_ptr<OpenClRandomFactory> New(clcuda::Queue queue) {
+    return std::shared_ptr<OpenClRandomFactory>(new OpenClRandomFactory(queue));
+  }
+  OpenClRandom* CreateRandom(uint64_t size, random_seed_t seed) { return new OpenClRandom(queue_, size, seed); }
+
+ private:
+  explicit OpenClRandomFactory(clcuda::Queue queue) : queue_(queue) {}
+  clcuda::Queue queue_;
+};
+
+// random.h:70-79: fill `base` from a host generator, copy to `norm`, normalise rows of `cols`
+void RandomAndNormalize(clcuda::Queue* queue, const std::function<Float()>& gen, clcuda::Buffer<Float>* base,
+                        clcuda::Buffer<Float>* norm, uint32_t cols);
+// random.cc:159-167
+void RandomGammaAndNormalize(clcuda::Queue* queue, Float eta0, Float eta1, RowPartitionedMatrix<Float>* norm,
+                             clcuda::Buffer<Float>* sum);
+
+}  // namespace random
+
+class NeighborSampler {
+ public:
+  NeighborSampler(const Config& cfg, clcuda::Queue queue);
+  void operator()(uint32_t num_samples, clcuda::Buffer<Vertex>* nodes);
+  clcuda::Buffer<Vertex>& GetHash() { return hash_; }
+  clcuda::Buffer<Vertex>& GetData() { return data_; }
+  uint32_t HashCapacityPerSample() { return capacity_; }
+  uint32_t DataSizePerSample() { return n_; }
+
+ private:
+  std::shared_ptr<ammsb_ctx> ctx_;
+  clcuda::Queue queue_;
+  uint32_t n_, capacity_, local_;
+  uint64_t max_nodes_;
+  clcuda::Buffer<Vertex> hash_, data_;
+  random::OpenClRandom rand_;
+};
+
+struct Sample {  // sample.h:51-92
+  clcuda::Queue queue;
+  std::vector<Edge> edges;
+  clcuda::Buffer<Edge> dev_edges;
+  std::vector<Vertex> nodes_vec;
+  clcuda::Buffer<Vertex> dev_nodes;
+  unsigned int seed;
+  NeighborSampler neighbor_sampler;
+  Sample(const Config& cfg, clcuda::Queue queue);                     // seed = rand(), as sample.cc:132
+  Sample(const Config& cfg, clcuda::Queue queue, unsigned int seed);  // reproducible
+};
+
+class PhiUpdater {
+ public:
+  PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta, RowPartitionedMatrix<Float>* pi,
+             clcuda::Buffer<Float>& phi, OpenClSet* trainingSet, const std::vector<std::string>& compileFlags = {},
+             const std::string& baseFuncs = "");
+  void operator()(clcuda::Buffer<Vertex>& mini_batch_nodes, clcuda::Buffer<Vertex>& neighbors,
+                  uint32_t num_mini_batch_nodes);
+  uint64_t UpdatePhiTime() const { return t_update_phi_; }  // ns of device time (hip events)
+  uint64_t UpdatePiTime() const { return t_update_pi_; }
+  clcuda::Buffer<Float>& GetPhiVec() { return phi_vec_; }
+
+ private:
+  std::shared_ptr<ammsb_ctx> ctx_;
+  clcuda::Queue queue_;
+  clcuda::Buffer<Float>& beta_;
+  RowPartitionedMatrix<Float>* pi_;
+  clcuda::Buffer<Float>& phi_;
+  OpenClSet* trainingSet_;
+  uint64_t max_nodes_;
+  clcuda::Buffer<Float> phi_vec_;
+  random::OpenClRandom rand_;
+  uint32_t count_calls_, local_, flags_;
+  uint64_t t_update_phi_, t_update_pi_;
+};
+
+class BetaUpdater {
+ public:
+  enum Mode { EDGE_PER_THREAD, EDGE_PER_WORKGROUP };
+  BetaUpdater(Mode mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& theta,
+              clcuda::Buffer<Float>& beta, RowPartitionedMatrix<Float>* pi, OpenClSet* trainingSet,
+              const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
+  void operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale);
+  clcuda::Buffer<Float>& GetGrads() { return grads_; }
+
+ private:
+  std::shared_ptr<ammsb_ctx> ctx_;
+  clcuda::Queue queue_;
+  clcuda::Buffer<Float>& theta_;
+  clcuda::Buffer<Float>& beta_;
+  RowPartitionedMatrix<Float>* pi_;
+  OpenClSet* trainingSet_;
+  random::OpenClRandom rand_;
+  uint32_t count_calls_, local_;
+  clcuda::Buffer<Float> grads_;
+};
+
+class PerplexityCalculator {
+ public:
+  enum Mode { EDGE_PER_THREAD, EDGE_PER_WORKGROUP };
+  PerplexityCalculator(Mode mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
+                       RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Edge>& edges, OpenClSet* edgeSet,
+                       const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
+  Float operator()();  // returns -average log-likelihood (perplexity.cc:273)
+
+ private:
+  std::shared_ptr<ammsb_ctx> ctx_;
+  clcuda::Queue queue_;
+  clcuda::Buffer<Float>& beta_;
+  RowPartitionedMatrix<Float>* pi_;
+  clcuda::Buffer<Edge>& edges_;
+  OpenClSet* edgeSet_;
+  clcuda::Buffer<Float> ppx_per_edge_;
+  clcuda::Buffer<ammsb_ppx_sums> sums_;
+  uint32_t count_calls_, local_;
+};
+
+}  // namespace mcmc
+
+#endif  // MCMC_AMD_OPERATORS_H_

@@ -42,6 +42,8 @@ Config::Config() {  // config.h:69-101
   phi_vector_width = 1;
   sum_grads_vector_width = 1;
   device_sampling = false;
+  sample_seed[0] = 1804289383u;
+  sample_seed[1] = 846930886u;
 }
 
 std::ostream& operator<<(std::ostream& out, const ulong2& v) { return out << v[0] << "," << v[1]; }

@@ -1,0 +1,126 @@
+// mcmc::Learner (include/mcmc/learner.h): the reference's orchestration (mcmc/learner.cc:77-299) on
+// top of the C-ABI-backed operators.  Same allocation order, same initialisation (theta_0 from
+// std::mt19937(6342455113) + std::gamma_distribution, pi_0 from the device gamma streams {11,113}),
+// same loop: join the sample produced in the background, start the next one, phi, pi, beta.
+#include "mcmc/learner.h"
+
+#include <chrono>
+#include <cmath>
+#include <iostream>
+#include <random>
+#include <stdexcept>
+
+using namespace std::chrono;
+
+namespace mcmc {
+
+namespace {
+clcuda::Buffer<Edge> Upload(const clcuda::Queue& q, const std::vector<Edge>& v) {
+  return clcuda::Buffer<Edge>(q.GetContext(), q, v.begin(), v.end());
+}
+}  // namespace
+
+Learner::Learner(const Config& cfg, clcuda::Queue queue)
+    : cfg_(cfg),
+      queue_(queue),
+      beta_(queue_.GetContext(), 2 * cfg_.K),
+      theta_(queue_.GetContext(), 2 * cfg_.K),
+      allocFactory_(RowPartitionedMatrixFactory<Float>::New(queue_)),
+      pi_(allocFactory_->CreateMatrix(static_cast<uint32_t>(cfg_.N), static_cast<uint32_t>(cfg_.K))),
+      phi_(queue_.GetContext(), cfg_.N),
+      setFactory_(OpenClSetFactory::New(queue_)),
+      trainingSet_(setFactory_->CreateSet(*cfg_.training)),
+      heldoutSet_(setFactory_->CreateSet(*cfg_.heldout)),
+      heldoutEdges_(Upload(queue_, cfg_.heldout_edges)),
+      heldoutPerplexity_(PerplexityCalculator::EDGE_PER_WORKGROUP, cfg_, queue_, beta_, pi_.get(), heldoutEdges_,
+                         heldoutSet_.get()),
+      phiUpdater_(cfg_, queue_, beta_, pi_.get(), phi_, trainingSet_.get()),
+      betaUpdater_(BetaUpdater::EDGE_PER_WORKGROUP, cfg_, queue_, theta_, beta_, pi_.get(), trainingSet_.get()),
+      sampler_(GetSampler(cfg_.strategy)),
+      stepCount_(1),
+      time_(0),
+      samplingTime_(0),
+      edges_done_(0),
+      phase_(0) {
+  if (!sampler_) throw std::runtime_error("Unkown sample strategy");  // learner.cc:146
+  samples_[0].reset(new Sample(cfg_, queue_, cfg_.sample_seed[0]));
+  samples_[1].reset(new Sample(cfg_, queue_, cfg_.sample_seed[1]));
+  std::mt19937 mt19937(6342455113);  // learner.cc:150-153
+  std::gamma_distribution<Float> gamma_distribution(cfg_.eta0, cfg_.eta1);
+  auto gamma = std::bind(gamma_distribution, mt19937);
+  random::RandomAndNormalize(&queue_, gamma, &theta_, &beta_, 2);
+  random::RandomGammaAndNormalize(&queue_, cfg_.eta0, cfg_.eta1, pi_.get(), &phi_);  // learner.cc:154-155
+}
+
+Learner::~Learner() {
+  for (auto& f : futures_)
+    if (f.valid()) f.wait();
+}
+
+Float Learner::DoSample(Sample* sample) {
+  sample->edges.clear();
+  const Float weight = sampler_(cfg_, &sample->edges, &sample->seed);
+  ExtractNodesFromMiniBatch(sample->edges, &sample->nodes_vec);
+  if (sample->nodes_vec.empty()) throw std::runtime_error("mini-batch size = 0!");
+  if (sample->edges.size() > sample->dev_edges.Count() || sample->nodes_vec.size() > sample->dev_nodes.Count())
+    throw std::runtime_error("mini-batch larger than its device buffers");  // learner.cc:184-189
+  sample->dev_edges.Write(sample->queue, sample->edges.size(), sample->edges.data());
+  sample->dev_nodes.Write(sample->queue, sample->nodes_vec.size(), sample->nodes_vec.data());
+  sample->neighbor_sampler(static_cast<uint32_t>(sample->nodes_vec.size()), &sample->dev_nodes);
+  return weight;
+}
+
+Float Learner::HeldoutPerplexity() {
+  const auto t1 = high_resolution_clock::now();
+  const Float ppx = heldoutPerplexity_();
+  time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
+  return std::exp(ppx);
+}
+
+void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
+  const auto t1 = high_resolution_clock::now();
+  if (stepCount_ == 1 && !futures_[phase_].valid())
+    futures_[phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[phase_].get());
+  for (uint64_t i = 0; i < max_iters && (signaled ? !*signaled : true); ++i, ++stepCount_) {
+    const auto ts = high_resolution_clock::now();
+    const Float weight = futures_[phase_].get();
+    futures_[1 - phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[1 - phase_].get());
+    samplingTime_ += duration_cast<nanoseconds>(high_resolution_clock::now() - ts).count();
+    Sample& s = *samples_[phase_];
+    phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), static_cast<uint32_t>(s.nodes_vec.size()));
+    betaUpdater_(&s.dev_edges, static_cast<uint32_t>(s.edges.size()), weight);
+    edges_done_ += s.edges.size();
+    phase_ = 1 - phase_;
+  }
+  time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
+}
+
+void Learner::PrintStats(std::ostream& out) {
+  const double total = time_ / 1.0e9;
+  auto pct = [&](double v) { return total > 0 ? 100 * v / total : 0.0; };
+  out << "TOTAL    : " << total << "\n";
+  out << "SAMPLING : " << samplingTime_ / 1.0e9 << " (%" << pct(samplingTime_ / 1.0e9) << ")\n";
+  out << "PHI      : " << phiUpdater_.UpdatePhiTime() / 1.0e9 << " (%" << pct(phiUpdater_.UpdatePhiTime() / 1.0e9) << ")\n";
+  out << "PI       : " << phiUpdater_.UpdatePiTime() / 1.0e9 << " (%" << pct(phiUpdater_.UpdatePiTime() / 1.0e9) << ")\n";
+}
+
+void Learner::PrintStats() { PrintStats(std::cerr); }
+
+std::vector<Float> Learner::GetBeta() {
+  std::vector<Float> v(2 * cfg_.K);
+  beta_.Read(queue_, v.size(), v.data());
+  return v;
+}
+std::vector<Float> Learner::GetTheta() {
+  std::vector<Float> v(2 * cfg_.K);
+  theta_.Read(queue_, v.size(), v.data());
+  return v;
+}
+std::vector<Float> Learner::GetPiRow(Vertex v) {
+  std::vector<Float> row(cfg_.K);
+  const uint32_t blk = v / pi_->RowsPerBlock();
+  pi_->Blocks()[blk].Read(queue_, cfg_.K, row.data(), (size_t)(v % pi_->RowsPerBlock()) * cfg_.K);
+  return row;
+}
+
+}  // namespace mcmc

@@ -1,0 +1,283 @@
+// The reference's operator classes as thin forwards to the C ABI (include/mcmc/operators.h).
+#include "mcmc/operators.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <tuple>
+
+namespace mcmc {
+
+void ThrowIfError(ammsb_ctx* ctx, int rc, const char* what) {
+  if (rc == AMMSB_OK) return;
+  throw std::runtime_error(std::string(what) + ": " + ammsb_strerror(rc) + " (" + ammsb_last_error(ctx) + ")");
+}
+
+std::shared_ptr<ammsb_ctx> AcquireContext(const Config& cfg, const clcuda::Queue& queue) {
+  const ammsb_params p = MakeKernelParams(cfg);
+  ammsb_ctx* ctx = nullptr;
+  const int rc = ammsb_ctx_create(queue.device(), &p, &ctx);
+  if (rc != AMMSB_OK) throw std::runtime_error(std::string("ammsb_ctx_create: ") + ammsb_strerror(rc));
+  return std::shared_ptr<ammsb_ctx>(ctx, [](ammsb_ctx* c) { ammsb_ctx_destroy(c); });
+}
+
+namespace {
+uint64_t MaxNodes(const Config& cfg) {  // phi.cc:620-622
+  return std::max<uint64_t>(2 * cfg.mini_batch_size, 1 + cfg.trainingGraph->MaxFanOut());
+}
+uint64_t MaxEdges(const Config& cfg) {  // sample.cc:129
+  return std::max<uint64_t>(cfg.mini_batch_size, cfg.trainingGraph->MaxFanOut());
+}
+}  // namespace
+
+// ------------------------------------------------------------------ RowPartitionedMatrix
+
+template <class T>
+RowPartitionedMatrix<T>::RowPartitionedMatrix(clcuda::Queue queue, uint32_t rows, uint32_t cols, uint32_t rows_in_block)
+    : queue_(queue), rows_(rows), cols_(cols) {
+  // partitioned-alloc.h:122-131 sizes blocks by the device's maximum allocation; on MI355X that is the
+  // whole HBM, so the default is a single block.
+  rows_per_alloc_ = rows_in_block ? rows_in_block : rows;
+  const clcuda::Context ctx = queue_.GetContext();
+  for (uint32_t i = 0; i < rows_ / rows_per_alloc_; ++i) blocks_.emplace_back(ctx, (size_t)rows_per_alloc_ * cols_);
+  if (rows_ % rows_per_alloc_) blocks_.emplace_back(ctx, (size_t)(rows_ % rows_per_alloc_) * cols_);
+  if (blocks_.size() > AMMSB_RPM_MAX_BLOCKS) throw std::runtime_error("more than 32 blocks");
+  std::memset(&desc_, 0, sizeof desc_);
+  for (size_t i = 0; i < blocks_.size(); ++i) desc_.blocks[i] = blocks_[i].data();
+  desc_.rows_in_block = rows_per_alloc_;
+  desc_.num_rows = rows_;
+  desc_.num_cols = cols_;
+  desc_.num_blocks = static_cast<uint32_t>(blocks_.size());
+}
+template class RowPartitionedMatrix<Float>;
+template class RowPartitionedMatrix<uint32_t>;
+
+// ------------------------------------------------------------------------------ OpenClSet
+
+OpenClSet::OpenClSet(clcuda::Queue queue, const Set& set) : data_(queue.GetContext(), set.Capacity()) {
+  data_.Write(queue, set.Capacity(), set.Data());  // cuckoo.cc:230-231
+  desc_.slots = data_.data();
+  desc_.num_bins = set.BinsPerBucket();
+  desc_.prime_idx = set.PrimeIdx();
+}
+
+// ---------------------------------------------------------------------------------- random
+
+namespace random {
+
+OpenClRandom::OpenClRandom(clcuda::Queue queue, uint64_t size, random_seed_t seed)
+    : queue_(queue), data_(queue.GetContext(), size) {
+  SetSeed(seed);
+}
+
+void OpenClRandom::SetSeed(random_seed_t seed) {
+  // ammsb_rng_init needs no context state; a null ctx is rejected, so use a throw-away one-element params
+  static std::mutex mu;
+  static std::map<int, std::shared_ptr<ammsb_ctx>> ctxs;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& c = ctxs[queue_.device()];
+  if (!c) {
+    ammsb_params p = {2, 1, 0, 1, 1.f, 1.f, 1.f, 1.f, 1e-7f, 1.f, 1.f};
+    ammsb_ctx* raw = nullptr;
+    ThrowIfError(nullptr, ammsb_ctx_create(queue_.device(), &p, &raw), "ammsb_ctx_create");
+    c.reset(raw, [](ammsb_ctx* x) { ammsb_ctx_destroy(x); });
+  }
+  ThrowIfError(c.get(), ammsb_rng_init(c.get(), data_.data(), data_.Count(), seed[0], seed[1], queue_.stream()),
+               "ammsb_rng_init");
+  queue_.Finish();  // random.cc:67-68
+}
+
+void RandomAndNormalize(clcuda::Queue* queue, const std::function<Float()>& gen, clcuda::Buffer<Float>* base,
+                        clcuda::Buffer<Float>* norm, uint32_t cols) {
+  if (cols != 2) throw std::runtime_error("RandomAndNormalize: only the (theta, beta) pair form is used");
+  std::vector<Float> host(base->Count());
+  for (Float& v : host) v = gen();
+  base->Write(*queue, host.size(), host.data());
+  // Normalizer(slice = 2, wg = 1), normalize.cc:13-32: lsum = (0 + a) + b
+  for (size_t k = 0; k + 1 < host.size(); k += 2) {
+    Float lsum = 0;
+    lsum += host[k];
+    lsum += host[k + 1];
+    host[k] = host[k] / lsum;
+    host[k + 1] = host[k + 1] / lsum;
+  }
+  norm->Write(*queue, host.size(), host.data());
+}
+
+void RandomGammaAndNormalize(clcuda::Queue* queue, Float eta0, Float eta1, RowPartitionedMatrix<Float>* norm,
+                             clcuda::Buffer<Float>* sum) {
+  OpenClRandom randv(*queue, (uint64_t)norm->Rows() * 32, random_seed_t{11, 113});  // random.cc:163-164
+  Config dummy;
+  dummy.N = norm->Rows();
+  dummy.K = norm->Cols();
+  std::shared_ptr<ammsb_ctx> ctx = AcquireContext(dummy, *queue);
+  ThrowIfError(ctx.get(),
+               ammsb_pi_init_gamma(ctx.get(), &norm->Get(), sum->data(), eta0, eta1, randv.Get(), queue->stream()),
+               "ammsb_pi_init_gamma");
+  queue->Finish();
+}
+
+}  // namespace random
+
+// ------------------------------------------------------------------------- NeighborSampler
+
+NeighborSampler::NeighborSampler(const Config& cfg, clcuda::Queue queue)
+    : ctx_(AcquireContext(cfg, queue)),
+      queue_(queue),
+      n_(static_cast<uint32_t>(cfg.num_node_sample)),
+      capacity_(2 * n_),
+      local_(cfg.neighbor_sampler_wg_size),
+      max_nodes_(MaxNodes(cfg)),
+      hash_(queue.GetContext(), max_nodes_ * capacity_),
+      data_(queue.GetContext(), max_nodes_ * n_),
+      rand_(queue, max_nodes_ * capacity_, cfg.neighbor_seed) {}
+
+void NeighborSampler::operator()(uint32_t num_samples, clcuda::Buffer<Vertex>* nodes) {
+  if (num_samples > max_nodes_) throw std::runtime_error("NeighborSampler: more samples than buffer rows");
+  ThrowIfError(ctx_.get(),
+               ammsb_sample_neighbors(ctx_.get(), rand_.Get(), nodes->data(), num_samples, local_, hash_.data(),
+                                      data_.data(), queue_.stream()),
+               "ammsb_sample_neighbors");
+  queue_.Finish();  // sample.cc:120
+}
+
+Sample::Sample(const Config& cfg, clcuda::Queue q, unsigned int s)
+    : queue(q.GetContext(), q.GetDevice()),
+      dev_edges(q.GetContext(), MaxEdges(cfg)),
+      dev_nodes(q.GetContext(), MaxNodes(cfg)),
+      seed(s),
+      neighbor_sampler(cfg, clcuda::Queue(q.GetContext(), q.GetDevice())) {}
+
+Sample::Sample(const Config& cfg, clcuda::Queue q) : Sample(cfg, q, static_cast<unsigned int>(rand())) {}
+
+// ------------------------------------------------------------------------------ PhiUpdater
+
+namespace {
+struct EventTimer {  // device time of one enqueue, like clcuda::Event::GetElapsedTime()
+  hipEvent_t a, b;
+  hipStream_t s;
+  explicit EventTimer(void* stream) : s(static_cast<hipStream_t>(stream)) {
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+  }
+  uint64_t StopNs() {
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return static_cast<uint64_t>(ms * 1e6);
+  }
+};
+}  // namespace
+
+PhiUpdater::PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
+                       RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Float>& phi, OpenClSet* trainingSet,
+                       const std::vector<std::string>&, const std::string&)
+    : ctx_(AcquireContext(cfg, queue)),
+      queue_(queue),
+      beta_(beta),
+      pi_(pi),
+      phi_(phi),
+      trainingSet_(trainingSet),
+      max_nodes_(MaxNodes(cfg)),
+      phi_vec_(queue.GetContext(), max_nodes_ * cfg.K),
+      rand_(queue, max_nodes_ * cfg.phi_wg_size, cfg.phi_seed),  // phi.cc:625-629
+      count_calls_(0),
+      local_(cfg.phi_wg_size),
+      flags_(cfg.phi_disable_noise ? AMMSB_NOISE_OFF : 0u),
+      t_update_phi_(0),
+      t_update_pi_(0) {}
+
+void PhiUpdater::operator()(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex>& neighbors, uint32_t n) {
+  if (n == 0) throw std::runtime_error("mini-batch nodes size = 0!");  // phi.cc:732
+  if (n > max_nodes_) throw std::runtime_error("grads too small");     // phi.cc:734-737
+  ++count_calls_;
+  {
+    EventTimer t(queue_.stream());
+    ThrowIfError(ctx_.get(),
+                 ammsb_update_phi(ctx_.get(), beta_.data(), &pi_->Get(), phi_.data(), &trainingSet_->Get(), nodes.data(),
+                                  neighbors.data(), n, count_calls_, rand_.Get(), local_, flags_, 0, 0xFFFFFFFFu,
+                                  phi_vec_.data(), queue_.stream()),
+                 "ammsb_update_phi");
+    t_update_phi_ += t.StopNs();  // phi.cc:755-757 (launch, Finish, elapsed)
+  }
+  {
+    EventTimer t(queue_.stream());
+    ThrowIfError(ctx_.get(),
+                 ammsb_update_pi(ctx_.get(), &pi_->Get(), phi_.data(), phi_vec_.data(), nodes.data(), n, local_,
+                                 queue_.stream()),
+                 "ammsb_update_pi");
+    t_update_pi_ += t.StopNs();
+  }
+}
+
+// ----------------------------------------------------------------------------- BetaUpdater
+
+BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& theta,
+                         clcuda::Buffer<Float>& beta, RowPartitionedMatrix<Float>* pi, OpenClSet* trainingSet,
+                         const std::vector<std::string>&, const std::string&)
+    : ctx_(AcquireContext(cfg, queue)),
+      queue_(queue),
+      theta_(theta),
+      beta_(beta),
+      pi_(pi),
+      trainingSet_(trainingSet),
+      rand_(queue, cfg.K, cfg.beta_seed),  // beta.cc:251-252
+      count_calls_(0),
+      local_(cfg.beta_wg_size),
+      grads_(queue.GetContext(), 2 * cfg.K) {}
+
+void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale) {
+  ++count_calls_;  // beta.cc:336
+  ThrowIfError(ctx_.get(),
+               ammsb_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), &trainingSet_->Get(), edges->data(),
+                                num_edges, 0, num_edges, local_, grads_.data(), queue_.stream()),
+               "ammsb_beta_grads");
+  ThrowIfError(ctx_.get(),
+               ammsb_update_theta(ctx_.get(), theta_.data(), beta_.data(), grads_.data(), count_calls_, scale, rand_.Get(),
+                                  0, queue_.stream()),
+               "ammsb_update_theta");
+  queue_.Finish();
+}
+
+// -------------------------------------------------------------------- PerplexityCalculator
+
+PerplexityCalculator::PerplexityCalculator(Mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
+                                           RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Edge>& edges,
+                                           OpenClSet* edgeSet, const std::vector<std::string>&, const std::string&)
+    : ctx_(AcquireContext(cfg, queue)),
+      queue_(queue),
+      beta_(beta),
+      pi_(pi),
+      edges_(edges),
+      edgeSet_(edgeSet),
+      ppx_per_edge_(queue.GetContext(), edges.Count()),
+      sums_(queue.GetContext(), 1),
+      count_calls_(0),
+      local_(cfg.ppx_wg_size) {
+  std::vector<Float> zero(edges.Count(), 0);  // perplexity.cc:204-205
+  ppx_per_edge_.Write(queue_, zero.size(), zero.data());
+}
+
+Float PerplexityCalculator::operator()() {
+  ++count_calls_;  // perplexity.cc:252
+  const uint32_t H = static_cast<uint32_t>(edges_.Count());
+  ThrowIfError(ctx_.get(),
+               ammsb_perplexity(ctx_.get(), beta_.data(), &pi_->Get(), &edgeSet_->Get(), edges_.data(), H, 0, H,
+                                count_calls_, local_, ppx_per_edge_.data(), sums_.data(), queue_.stream()),
+               "ammsb_perplexity");
+  ammsb_ppx_sums s;
+  sums_.Read(queue_, 1, &s);
+  double avg = 0.0;  // perplexity.cc:264-268
+  if (s.link_cnt + s.nonlink_cnt != 0) avg = (s.link_ll + s.nonlink_ll) / static_cast<double>(s.link_cnt + s.nonlink_cnt);
+  return static_cast<Float>(-avg);
+}
+
+}  // namespace mcmc

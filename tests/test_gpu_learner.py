@@ -116,3 +116,15 @@ def test_learner_is_deterministic(env, small_ds):
         lrn.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+def test_cpp_dropin_learner(env):
+    """tests/cpp/learner_test.cc: a caller written against the reference's C++ API (Config, Graph,
+    GenerateSetsFromEdges, clcuda::Queue, Learner::Run / HeldoutPerplexity) runs on the HIP path."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mcmc-ammsb-gpu_amd", "learner_test")
+    assert os.path.exists(exe), "build() did not produce learner_test"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout
