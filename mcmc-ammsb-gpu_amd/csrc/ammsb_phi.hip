@@ -357,12 +357,21 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
       }
     }
 
+    // The ring is idle now: slot 0 receives this node's K normals.  One rolled loop (a single copy of
+    // the ziggurat code with its binary64 tail, dynamic LDS index) instead of KPT inlined copies.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (a.noise_on) {
+#pragma unroll 1
+      for (int j = 0; j < KPT; ++j) ring[l + 64 * j] = rng_normal(rs, &zig);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
     // SGLD step, phi.cc:265-274
     float* out = a.phi_vec + i * K;
     const float half = a.eps_t / 2;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const float noise = a.noise_on ? rng_normal(rs, &zig) : 1.0f;
+      const float noise = a.noise_on ? ring[l + 64 * j] : 1.0f;
       const float phi_k = pi_a[j] * phi_sum;
       const float ng = a.Nn * grads[j];
       float in = a.alpha - phi_k;
