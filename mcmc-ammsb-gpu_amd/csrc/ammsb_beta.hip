@@ -13,6 +13,8 @@
 // not (see include/ammsb.h, ammsb_beta_grads).
 #pragma clang fp contract(off)
 
+#include <stdlib.h>
+
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
 
@@ -70,33 +72,55 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   const uint32_t trips = (n_edges + a.P - 1) / a.P;  // uniform
   int phase = 0;
 
-  // software pipeline: the two rows of edge t+1 are requested before edge t is consumed
-  float pa[2][KPT], pb[2][KPT];
-  uint64_t key[2] = {0, 0};
-  bool have[2] = {false, false};
-  // Loads are unconditional: an exhausted slot re-reads its first edge (results discarded) and a
-  // column beyond K re-reads column K-1 (its products are zeroed), so no load sits behind a branch.
+  // Software pipeline.  A slot walks edges e(t) = edge_begin + gs + t * P.  Two dependent latencies sit
+  // in front of every edge (its key, then its two rows); both are taken off the critical path:
+  //   keys: lane i of the group loads the key of trip tb + i AND probes the cuckoo set for it, one
+  //         batch of W = min(L, 64) trips at a time and one whole batch ahead; key and link bit are
+  //         handed out with a cross-lane read / a ballot mask.  (The probe is two 64-bit modulos and
+  //         two dependent 32-byte reads: done per edge by every lane it dominated the kernel.)
+  //   rows: requested two trips ahead into a three-deep register ring.
+  constexpr int W = L < 64 ? L : 64;
+  const int kl = threadIdx.x & (W - 1);  // lane within the key batch
+  const int wave_lane = threadIdx.x & 63;
+  auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + kl) * a.P;
+    const bool ok = live && (tb + kl) < trips && e < a.edge_end;
+    const unsigned long long edge = a.edges[ok ? e : a.edge_begin];  // an exhausted trip shadows the first edge
+    const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
+    *ymask = __ballot(set_has(a.set, make_edge(u, v)));  // bit = lane of the wave
+    return edge;
+  };
+  uint32_t tb = 0;
+  unsigned long long ym = 0, ym_next = 0;
+  unsigned long long kv = load_keys(0, &ym), kv_next = load_keys(W, &ym_next);
+
+  float pa[3][KPT], pb[3][KPT];
+  bool link[3] = {false, false, false};
+  bool have[3] = {false, false, false};
   auto fetch = [&](int b, uint32_t t) {
     const uint64_t e_raw = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
     have[b] = live && t < trips && e_raw < a.edge_end;
-    const uint64_t e = have[b] ? e_raw : a.edge_begin;
-    const uint64_t edge = a.edges[e];
+    const uint32_t rel = t - tb;  // 0 .. 2W-1 by construction
+    const bool first = rel < (uint32_t)W;
+    const uint32_t src = first ? rel : rel - W;                 // lane of the group's key batch
+    const unsigned long long edge = first ? __shfl(kv, (int)src, W) : __shfl(kv_next, (int)src, W);
+    const uint32_t bit = (wave_lane & ~(W - 1)) + src;          // that lane's position in the wave
+    link[b] = (((first ? ym : ym_next) >> bit) & 1ull) != 0;
     const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
-    key[b] = make_edge(u, v);
     const float* ra = rpm_row(a.pi, u);
     const float* rb = rpm_row(a.pi, v);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const uint32_t k = l + j * L;
-      const uint32_t ck = k < K ? k : K - 1;
+      const uint32_t ck = k < K ? k : K - 1;  // unconditional loads: a column beyond K shadows column K-1
       const float xa = ra[ck], xb = rb[ck];
       pa[b][j] = k < K ? xa : 0.0f;
       pb[b][j] = xb;
     }
   };
   auto consume = [&](int b) {
-    const bool y = set_has(a.set, key[b]);
-    float scratch = 0.0f, ppart = 0.0f;
+    const bool y = link[b];
+    float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
     float probs[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {  // CALC_PROBS, beta.cc:145-160
@@ -104,6 +128,8 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
       scratch += f;
       probs[j] = y ? bk[j] * f : omb[j] * f;
       ppart += probs[j];
+      const float m = fabsf(probs[j]);
+      lo = fminf(lo, m == 0.0f ? 1.0f : m);  // an exact zero divides exactly on either path
     }
     const float pi_sum = Grp::sum(scratch, aux, phase);  // beta.cc:209-213
     float probs_sum = Grp::sum(ppart, aux, phase);       // beta.cc:214-217
@@ -111,21 +137,44 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
     const float prob_0 = w * (1.0f - pi_sum);
     probs_sum += prob_0;
     if (have[b]) {
+      // CALC_GRADS, beta.cc:161-171.  probs[j] / probs_sum with the reciprocal refined once per edge
+      // (ammsb_dev.h "exact division"): exact when every numerator is 0 or at least 2^-100 in
+      // magnitude and the divisor is in range; otherwise the plain IEEE divide.
+      if (lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+        const float rps = refined_rcp(probs_sum);
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {  // CALC_GRADS, beta.cc:161-171
-        const float f = probs[j] / probs_sum;
-        acc0[j] += f * (y ? noo[j] : d0n[j]);
-        acc1[j] += f * (y ? d1l[j] : noo[j]);
+        for (int j = 0; j < KPT; ++j) {
+          const float f = div_with_rcp(probs[j], probs_sum, rps);
+          acc0[j] += f * (y ? noo[j] : d0n[j]);
+          acc1[j] += f * (y ? d1l[j] : noo[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+          const float f = probs[j] / probs_sum;
+          acc0[j] += f * (y ? noo[j] : d0n[j]);
+          acc1[j] += f * (y ? d1l[j] : noo[j]);
+        }
       }
     }
   };
 
   fetch(0, 0);
-  for (uint32_t t = 0; t < trips; t += 2) {
-    fetch(1, t + 1);
+  fetch(1, 1);
+  for (uint32_t t = 0; t < trips; t += 3) {
+    // trips t+2 .. t+4 stay inside [tb, tb + 2W): advance the key window when t leaves the first batch
+    if (t + 2 >= tb + 2 * W - 3) {
+      kv = kv_next;
+      ym = ym_next;
+      tb += W;
+      kv_next = load_keys(tb + W, &ym_next);
+    }
+    fetch(2, t + 2);
     consume(0);
-    fetch(0, t + 2);
+    fetch(0, t + 3);
     consume(1);
+    fetch(1, t + 4);
+    consume(2);
   }
 
   if (live) {
@@ -138,25 +187,24 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   }
 }
 
-// sum_grads: grads[c] = sum over the P partial rows, fixed order.  64 columns x 4 row-lanes per
-// block; row-lane r adds rows r, r+4, ... in ascending order, then the four are added 0+1+2+3.
+// sum_grads: grads[c] = sum over the P partial rows in a fixed order.  16 columns x 16 row-lanes per
+// block (2K/16 blocks, so the whole chip takes part): row-lane r adds rows r, r+16, ... ascending,
+// then the 16 lane sums are added by the halving tree r += r+8, +4, +2, +1.
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, uint32_t P, uint32_t cols,
                                                             float* out) {
-  __shared__ float red[4][64];
-  const uint32_t c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const uint32_t r = threadIdx.x >> 6;
+  __shared__ float red[16][17];
+  const uint32_t cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const uint32_t c = blockIdx.x * 16 + cl;
   float s = 0.0f;
   if (c < cols)
-    for (uint32_t p = r; p < P; p += 4) s += partials[(uint64_t)p * cols + c];
-  red[r][threadIdx.x & 63] = s;
+    for (uint32_t p = r; p < P; p += 16) s += partials[(uint64_t)p * cols + c];
+  red[r][cl] = s;
   __syncthreads();
-  if (r == 0 && c < cols) {
-    float t = red[0][threadIdx.x];
-    t += red[1][threadIdx.x];
-    t += red[2][threadIdx.x];
-    t += red[3][threadIdx.x];
-    out[c] = t;
+  for (uint32_t h = 8; h > 0; h >>= 1) {
+    if (r < h) red[r][cl] += red[r + h][cl];
+    __syncthreads();
   }
+  if (r == 0 && c < cols) out[c] = red[0][cl];
 }
 
 // update_theta (beta.cc:51-82) + beta = pair-normalised theta (beta.cc:376-383; Normalizer slice 2,
@@ -287,6 +335,7 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
   const uint32_t span = edge_end - edge_begin;
   // enough slots to fill the chip (~8 waves per CU), never more than there are edges
   uint32_t want = (uint32_t)ctx->num_cus * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
+  if (const char* ov = getenv("AMMSB_BETA_SLOTS")) want = (uint32_t)atoi(ov);  // tuning override
   if (want < 64) want = 64;
   if (want > ctx->max_partials) want = ctx->max_partials;
   a.P = span < want ? span : want;
@@ -294,7 +343,7 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
                          int rc = launch_grads<L_, KPT_>(ctx, a, s);
                          if (rc) return rc;
                        }));
-  sum_partials_kernel<<<(2 * K + 63) / 64, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
+  sum_partials_kernel<<<(2 * K + 15) / 16, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--ppx-wgs", default="64,128,256")
     ap.add_argument("--noise", type=int, default=1)
     ap.add_argument("--only", default="phi,pi,beta,ppx")
+    ap.add_argument("--beta-random", type=int, default=0, help="1: both end points random (no shared row)")
     args = ap.parse_args()
     N, K, m, n = args.N, args.K, args.m, args.n
     rng = np.random.default_rng(0)
@@ -78,6 +79,8 @@ def main():
                       (wg, med, mn, 8 * K * nn / med / 1e6), flush=True)
             del upd
     mb = (np.uint64(12345) << np.uint64(32)) | rng.permutation(N)[:m].astype(np.uint64)
+    if args.beta_random:
+        mb = (rng.integers(0, N, m, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, N, m, dtype=np.uint64)
     dev_edges = ctx.from_numpy(mb)
     if "beta" in only:
         for wg in [int(x) for x in args.beta_wgs.split(",")]:
