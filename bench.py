@@ -202,7 +202,7 @@ def main():
         achieved = per_node * nodes_per_launch / avg_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "phi_traffic.json")
-        if os.path.exists(tpath):
+        if args.workload == "C3" and world == 1 and os.path.exists(tpath):  # the PMC passes were taken on this case
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:

@@ -9,9 +9,11 @@ the reference does not have.
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): pi, phi_sum, beta/theta and both
 cuckoo sets are replicated; the mini-batch is the same on every rank (same seeds).  Per iteration
-    phi    rank r runs virtual groups [r*C, (r+1)*C), C = ceil(65535/R) -- a fixed ownership of RNG
-           streams, so no stream state ever crosses ranks -- then the phi_vec rows are all-gathered
-           and every rank applies update_pi to all mini-batch nodes;
+    phi    the 65535 virtual groups are cut into blocks of Cc = ceil(65535 / (R * chunks)); block b
+           belongs to rank b % R and is processed in chunk b // R -- a fixed ownership of RNG streams,
+           so no stream state ever crosses ranks and results do not depend on R.  Chunk c's rows
+           (one block per rank, contiguous) are all-gathered asynchronously while chunk c+1 is being
+           computed; update_pi runs on every rank over all nodes once every chunk has arrived;
     beta   rank r sums the gradient over its contiguous slice of the mini-batch edges; the R partial
            [2K] vectors are all-gathered and added in rank order; every rank runs the identical
            update_theta (same streams) -> no broadcast;
@@ -54,6 +56,7 @@ class Config:
         self.device_sampling = False                 # (new) draw mini-batches on the device
         self.device_sampling_seed = (1234, 5678)     # (new)
         self.sample_parallel = True                  # MCMC_SAMPLE_PARALLEL, CMakeLists.txt:42
+        self.phi_chunks = 4                          # (new) multi-GPU: phi launches per iteration (exchange overlap)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown Config field %s" % k)
@@ -119,8 +122,10 @@ class Learner:
         if self.heldoutSet is None:
             raise AmmsbError("held-out set is empty: raise heldout_ratio")
         max_nodes = dataset.max_nodes(cfg.mini_batch_size)
-        self.chunk = (MAX_GROUPS + self.world - 1) // self.world  # phi groups owned per rank
-        phi_rows = max(max_nodes, self.chunk * self.world if self.world > 1 else 0)
+        self.nch = max(1, int(cfg.phi_chunks)) if self.world > 1 else 1
+        blocks = self.world * self.nch
+        self.cc = (MAX_GROUPS + blocks - 1) // blocks  # groups per (rank, chunk) block
+        phi_rows = max(max_nodes, self.cc * blocks if self.world > 1 else 0)
         # learner.cc:105-116
         self.heldoutPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.heldoutEdges,
                                                           self.heldoutSet, cfg.ppx_wg_size)
@@ -146,6 +151,7 @@ class Learner:
         if self.world > 1:
             self.all_grads = c.zeros((self.world, 2 * K), torch.float32)
             self.all_sums = c.zeros((self.world, 4), torch.int64)
+            self.tail_buf = c.zeros((max(max_nodes - MAX_GROUPS, 1), K), torch.float32)
         # learner.cc:150-155: theta_0 (host std::gamma) -> beta_0; pi_0 / phi_sum_0 (device gamma {11,113})
         from . import hostlib
         self.theta.copy_(c.from_numpy(hostlib.theta_init(K, cfg.eta0, cfg.eta1)))
@@ -197,31 +203,45 @@ class Learner:
         import torch.distributed as dist
         return dist
 
-    def _group_range(self, n_nodes):
-        G = min(n_nodes, MAX_GROUPS)
-        lo = min(self.rank * self.chunk, G)
-        hi = min((self.rank + 1) * self.chunk, G)
-        return G, lo, hi
-
-    def _exchange_phi_vec(self, n_nodes):
+    def _phi_sharded(self, s, n_nodes):
+        """update_phi over this rank's blocks, chunk by chunk, with the phi_vec exchange overlapped."""
+        ops, phi = self.ops, self.phiUpdater
+        nodes, nbrs = s.dev_nodes, s.neighbor_sampler.GetData()
         if self.world == 1:
+            phi.update_phi(nodes, nbrs, n_nodes)
             return
         dist = self._dist()
-        pv = self.phiUpdater.phi_vec
+        pv = phi.phi_vec
+        R, r, Cc = self.world, self.rank, self.cc
         G = min(n_nodes, MAX_GROUPS)
-        active = (G + self.chunk - 1) // self.chunk  # ranks that own at least one live group
-        if active <= 1:
-            dist.broadcast(pv[:n_nodes], src=0, group=self.group)  # includes the tail rows (all rank 0's)
-            return
-        # Tail rows i >= G belong to the rank owning group i - G.  They are broadcast FIRST: a tail row
-        # can lie inside another rank's all-gather chunk (row 65535 sits in the last chunk), and the
-        # in-place all-gather below would otherwise overwrite the owner's value with a stale one.
         tail = n_nodes - G
-        for r in range(self.world):
-            lo, hi = r * self.chunk, min((r + 1) * self.chunk, tail)
+        live_chunks = (G + R * Cc - 1) // (R * Cc)  # chunks that contain at least one live group
+        works = []
+        for c in range(live_chunks):
+            lo = (c * R + r) * Cc
+            hi = min(lo + Cc, G)
             if lo < hi:
-                dist.broadcast(pv[G + lo:G + hi], src=r, group=self.group)
-        self.ops.all_gather_rows(dist, pv, self.chunk, self.rank, self.world, self.group)
+                phi.update_phi(nodes, nbrs, n_nodes, lo, hi)
+            base = c * R * Cc
+            last = c == live_chunks - 1
+            if last and tail > 0:
+                # Tail rows i >= G (second node of groups 0 .. tail-1) can lie inside this chunk's
+                # all-gather region; park each owner's tail rows before the region is overwritten.
+                for b0 in range(0, tail, Cc):
+                    if (b0 // Cc) % R == r:
+                        b1 = min(b0 + Cc, tail)
+                        self.tail_buf[b0:b1].copy_(pv[G + b0:G + b1])
+            if G - base <= Cc:  # only rank 0's block is live in this chunk: a broadcast is enough
+                works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
+            else:
+                works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group))
+        for w in works:
+            ops.wait_work(w)
+        for b0 in range(0, tail, Cc):  # owners hand out their parked tail rows
+            b1 = min(b0 + Cc, tail)
+            dist.broadcast(self.tail_buf[b0:b1], src=(b0 // Cc) % R, group=self.group)
+        if tail > 0:
+            pv[G:G + tail].copy_(self.tail_buf[:tail])
 
     def _edge_range(self, n_edges):
         per = (n_edges + self.world - 1) // self.world
@@ -262,12 +282,9 @@ class Learner:
             # phiUpdater_(nodes, neighbors, n)  -- phi.cc:728-763
             phi = self.phiUpdater
             phi.count_calls += 1
-            G, lo, hi = self._group_range(n_nodes)
             if n_nodes == 0:
                 raise AmmsbError("mini-batch nodes size = 0!")
-            if lo < hi:
-                phi.update_phi(s.dev_nodes, s.neighbor_sampler.GetData(), n_nodes, lo, hi)
-            self._exchange_phi_vec(n_nodes)
+            self._phi_sharded(s, n_nodes)
             phi.update_pi(s.dev_nodes, n_nodes)
 
             # betaUpdater_(edges, n, weight)  -- beta.cc:334-384

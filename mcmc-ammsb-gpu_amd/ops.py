@@ -436,10 +436,20 @@ def pinned(shape, dtype):
     return torch.empty(shape, dtype=dtype, pin_memory=True)
 
 
-def all_gather_rows(dist, buf, chunk, rank, world, group):
-    """In-place all-gather of `world` equal row chunks of buf[:world*chunk] (rank r owns chunk r).
-    RCCL's in-place form (send buffer = its own slot of the receive buffer) moves each chunk once."""
-    dist.all_gather_into_tensor(buf[: world * chunk], buf[rank * chunk:(rank + 1) * chunk], group=group)
+def all_gather_rows_async(dist, region, chunk, rank, world, group):
+    """In-place all-gather of the `world` equal row chunks of `region` (rank r owns chunk r), issued
+    asynchronously: RCCL runs it on its own stream behind the work already queued on the current one,
+    so the next phi launch overlaps it.  The in-place form (send buffer = own slot of the receive
+    buffer) moves each chunk once."""
+    return dist.all_gather_into_tensor(region, region[rank * chunk:(rank + 1) * chunk], group=group, async_op=True)
+
+
+def broadcast_async(dist, rows, src, group):
+    return dist.broadcast(rows, src=src, group=group, async_op=True)
+
+
+def wait_work(work):
+    work.wait()  # makes the current stream wait for the collective; does not block the host
 
 
 def all_gather_flat(dist, out, local, rank, world, group):

@@ -254,11 +254,26 @@ def pinned(shape, dtype):
     return torch.zeros(shape, dtype=dtype)
 
 
-def all_gather_rows(dist, buf, chunk, rank, world, group):
-    parts = [torch.zeros_like(buf[:chunk]) for _ in range(world)]
-    dist.all_gather(parts, buf[rank * chunk:(rank + 1) * chunk].clone(), group=group)
+class _Done:
+    def wait(self):
+        pass
+
+
+def all_gather_rows_async(dist, region, chunk, rank, world, group):
+    parts = [torch.zeros_like(region[:chunk]) for _ in range(world)]
+    dist.all_gather(parts, region[rank * chunk:(rank + 1) * chunk].clone(), group=group)
     for r in range(world):
-        buf[r * chunk:(r + 1) * chunk] = parts[r]
+        region[r * chunk:(r + 1) * chunk] = parts[r]
+    return _Done()
+
+
+def broadcast_async(dist, rows, src, group):
+    dist.broadcast(rows, src=src, group=group)
+    return _Done()
+
+
+def wait_work(work):
+    work.wait()
 
 
 def all_gather_flat(dist, out, local, rank, world, group):

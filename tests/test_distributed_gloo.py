@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, outdir, case):
+def _run(rank, world, port, outdir, case, chunks=4):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,7 +41,7 @@ def _run(rank, world, port, outdir, case):
     edges = hostlib.generate_graph(N, 8, 12, seed=5)
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
     cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=32, beta_wg_size=32,
-                                           ppx_wg_size=32, strategy="Node", sample_parallel=True)
+                                           ppx_wg_size=32, strategy="Node", sample_parallel=True, phi_chunks=chunks)
     lrn = learner.Learner(cfg, ds, ops=oracle_ops, rank=rank, world_size=world, group=group)
     p0 = lrn.HeldoutPerplexity()
     lrn.Run(1)
@@ -58,11 +58,12 @@ def _run(rank, world, port, outdir, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", [
-    (3000, 32, 256, 8, 6),        # link + non-link batches, everything owned by rank 0's group range or split
-    (150000, 32, 70000, 2, 2),    # > 65535 mini-batch nodes: both ranks own groups, tail rows beyond group 65534
-], ids=["small", "tail"])
-def test_world2_matches_single_process(tmp_path, case):
+@pytest.mark.parametrize("case,chunks", [
+    ((3000, 32, 256, 8, 6), 4),        # link + non-link batches; only the first block is live -> broadcasts
+    ((150000, 32, 70000, 2, 2), 1),    # > 65535 mini-batch nodes: both ranks own groups, tail rows beyond group 65534
+    ((150000, 32, 70000, 2, 2), 3),    # same with the exchange cut into 3 overlapped chunks
+], ids=["small", "tail-1chunk", "tail-3chunks"])
+def test_world2_matches_single_process(tmp_path, case, chunks):
     import torch.multiprocessing as mp
     import __graft_entry__ as ge
     ge.build()
@@ -70,7 +71,7 @@ def test_world2_matches_single_process(tmp_path, case):
     _run(0, 1, 0, out, case)
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -90,14 +91,15 @@ def test_world2_matches_single_process(tmp_path, case):
     assert np.allclose(r0["theta"], one["theta"], rtol=2e-5, atol=1e-7)
     assert np.allclose(r0["pi"], one["pi"], rtol=5e-4, atol=1e-7)
     assert abs(r0["ppx"][1] - one["ppx"][1]) <= 1e-5 * one["ppx"][1]
-    # stream ownership is fixed: the union of the two ranks' advanced streams equals the single-process state
-    chunk = (65535 + 1) // 2
+    # stream ownership is fixed (block b of Cc groups belongs to rank b % 2): each rank advanced exactly
+    # its own blocks' streams, and their union equals the single-process state
     L = 32
+    cc = (65535 + 2 * chunks - 1) // (2 * chunks)
     s0, s1, s = r0["seeds"].reshape(-1, 2), r1["seeds"].reshape(-1, 2), one["seeds"].reshape(-1, 2)
-    lim = min(s.shape[0], chunk * L)
-    assert np.array_equal(s0[:lim], s[:lim])
-    if s.shape[0] > chunk * L:
-        assert np.array_equal(s1[chunk * L:], s[chunk * L:])
+    lim = min(s.shape[0], s0.shape[0], 65535 * L)
+    owner = (np.arange(lim) // L // cc) % 2
+    assert np.array_equal(s0[:lim][owner == 0], s[:lim][owner == 0])
+    assert np.array_equal(s1[:lim][owner == 1], s[:lim][owner == 1])
     # perplexity state: each rank owns a contiguous slice of the held-out edges
     H = one["ppx_state"].size
     per = (H + 1) // 2
