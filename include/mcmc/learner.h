@@ -5,6 +5,7 @@
 #include <signal.h>
 
 #include <future>
+#include <istream>
 #include <memory>
 #include <ostream>
 
@@ -23,6 +24,8 @@ class Learner {
   Float HeldoutPerplexity();                                       // learner.cc:196-203
   void PrintStats(std::ostream& out);                              // learner.cc:252-299
   void PrintStats();
+  bool Serialize(std::ostream* out);  // learner.cc:301-330
+  bool Parse(std::istream* in);       // learner.cc:332-363
 
   // read-back helpers for tests / drivers (not in the reference API)
   std::vector<Float> GetBeta();

@@ -14,7 +14,9 @@
 #define MCMC_AMD_OPERATORS_H_
 
 #include <functional>
+#include <istream>
 #include <memory>
+#include <ostream>
 #include <string>
 #include <vector>
 
@@ -92,6 +94,8 @@ class OpenClRandom {
   void SetSeed(random_seed_t seed);
   clcuda::Buffer<ammsb_seed>& GetSeeds() { return data_; }
   ammsb_seed* Get() { return data_.data(); }
+  bool Serialize(std::ostream* out);  // random.cc:71-77
+  bool Parse(std::istream* in);
 
  private:
   clcuda::Queue queue_;
@@ -127,6 +131,8 @@ class NeighborSampler {
   clcuda::Buffer<Vertex>& GetData() { return data_; }
   uint32_t HashCapacityPerSample() { return capacity_; }
   uint32_t DataSizePerSample() { return n_; }
+  bool Serialize(std::ostream* out);  // sample.h:30-36
+  bool Parse(std::istream* in);
 
  private:
   std::shared_ptr<ammsb_ctx> ctx_;
@@ -147,6 +153,8 @@ struct Sample {  // sample.h:51-92
   NeighborSampler neighbor_sampler;
   Sample(const Config& cfg, clcuda::Queue queue);                     // seed = rand(), as sample.cc:132
   Sample(const Config& cfg, clcuda::Queue queue, unsigned int seed);  // reproducible
+  bool Serialize(std::ostream* out);  // sample.h:62-91
+  bool Parse(std::istream* in);
 };
 
 class PhiUpdater {
@@ -159,6 +167,8 @@ class PhiUpdater {
   uint64_t UpdatePhiTime() const { return t_update_phi_; }  // ns of device time (hip events)
   uint64_t UpdatePiTime() const { return t_update_pi_; }
   clcuda::Buffer<Float>& GetPhiVec() { return phi_vec_; }
+  bool Serialize(std::ostream* out);  // phi.cc:765-784
+  bool Parse(std::istream* in);
 
  private:
   std::shared_ptr<ammsb_ctx> ctx_;
@@ -182,6 +192,8 @@ class BetaUpdater {
               const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
   void operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale);
   clcuda::Buffer<Float>& GetGrads() { return grads_; }
+  bool Serialize(std::ostream* out);  // beta.cc:386-413
+  bool Parse(std::istream* in);
 
  private:
   std::shared_ptr<ammsb_ctx> ctx_;
@@ -202,6 +214,8 @@ class PerplexityCalculator {
                        RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Edge>& edges, OpenClSet* edgeSet,
                        const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
   Float operator()();  // returns -average log-likelihood (perplexity.cc:273)
+  bool Serialize(std::ostream* out);  // perplexity.cc:276-293
+  bool Parse(std::istream* in);
 
  private:
   std::shared_ptr<ammsb_ctx> ctx_;

@@ -3,6 +3,7 @@
 // std::mt19937(6342455113) + std::gamma_distribution, pi_0 from the device gamma streams {11,113}),
 // same loop: join the sample produced in the background, start the next one, phi, pi, beta.
 #include "mcmc/learner.h"
+#include "mcmc/serialize.h"
 
 #include <chrono>
 #include <cmath>
@@ -93,6 +94,43 @@ void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
     phase_ = 1 - phase_;
   }
   time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
+}
+
+bool Learner::Serialize(std::ostream* out) {
+  LearnerProperties props;
+  props.stepCount = stepCount_;
+  props.time = time_;
+  props.samplingTime = samplingTime_;
+  props.phase = phase_;
+  if (!futures_[phase_].valid())  // the reference's constructor has the first sample in flight already
+    futures_[phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[phase_].get());
+  const Float weight = futures_[phase_].get();  // learner.cc:307-311: take the value, then re-arm the future
+  futures_[phase_] = std::async(std::launch::deferred, [weight]() -> Float { return weight; });
+  props.weight = weight;
+  queue_.Finish();
+  return ::mcmc::Serialize(out, &beta_, &queue_) && ::mcmc::Serialize(out, &theta_, &queue_) &&
+         ::mcmc::Serialize(out, pi_.get(), &queue_) && ::mcmc::Serialize(out, &phi_, &queue_) &&
+         phiUpdater_.Serialize(out) && betaUpdater_.Serialize(out) && heldoutPerplexity_.Serialize(out) &&
+         SerializeMessage(out, props) && samples_[0]->Serialize(out) && samples_[1]->Serialize(out);
+}
+
+bool Learner::Parse(std::istream* in) {
+  for (auto& f : futures_)
+    if (f.valid()) f.wait();
+  LearnerProperties props;
+  if (!(::mcmc::Parse(in, &beta_, &queue_) && ::mcmc::Parse(in, &theta_, &queue_) &&
+        ::mcmc::Parse(in, pi_.get(), &queue_) && ::mcmc::Parse(in, &phi_, &queue_) && phiUpdater_.Parse(in) &&
+        betaUpdater_.Parse(in) && heldoutPerplexity_.Parse(in) && ParseMessage(in, &props)))
+    return false;
+  stepCount_ = props.stepCount;
+  time_ = props.time;
+  samplingTime_ = props.samplingTime;
+  phase_ = props.phase & 1;
+  if (!(samples_[0]->Parse(in) && samples_[1]->Parse(in))) return false;
+  const Float weight = static_cast<Float>(props.weight);
+  futures_[1 - phase_] = std::future<Float>();
+  futures_[phase_] = std::async(std::launch::deferred, [weight]() -> Float { return weight; });
+  return true;
 }
 
 void Learner::PrintStats(std::ostream& out) {

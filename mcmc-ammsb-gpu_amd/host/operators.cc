@@ -1,5 +1,6 @@
 // The reference's operator classes as thin forwards to the C ABI (include/mcmc/operators.h).
 #include "mcmc/operators.h"
+#include "mcmc/serialize.h"
 
 #include <hip/hip_runtime.h>
 
@@ -91,6 +92,9 @@ void OpenClRandom::SetSeed(random_seed_t seed) {
   queue_.Finish();  // random.cc:67-68
 }
 
+bool OpenClRandom::Serialize(std::ostream* out) { return ::mcmc::Serialize(out, &data_, &queue_); }
+bool OpenClRandom::Parse(std::istream* in) { return ::mcmc::Parse(in, &data_, &queue_); }
+
 void RandomAndNormalize(clcuda::Queue* queue, const std::function<Float()>& gen, clcuda::Buffer<Float>* base,
                         clcuda::Buffer<Float>* norm, uint32_t cols) {
   if (cols != 2) throw std::runtime_error("RandomAndNormalize: only the (theta, beta) pair form is used");
@@ -145,6 +149,9 @@ void NeighborSampler::operator()(uint32_t num_samples, clcuda::Buffer<Vertex>* n
   queue_.Finish();  // sample.cc:120
 }
 
+bool NeighborSampler::Serialize(std::ostream* out) { return rand_.Serialize(out) && ::mcmc::Serialize(out, &data_, &queue_); }
+bool NeighborSampler::Parse(std::istream* in) { return rand_.Parse(in) && ::mcmc::Parse(in, &data_, &queue_); }
+
 Sample::Sample(const Config& cfg, clcuda::Queue q, unsigned int s)
     : queue(q.GetContext(), q.GetDevice()),
       dev_edges(q.GetContext(), MaxEdges(cfg)),
@@ -153,6 +160,28 @@ Sample::Sample(const Config& cfg, clcuda::Queue q, unsigned int s)
       neighbor_sampler(cfg, clcuda::Queue(q.GetContext(), q.GetDevice())) {}
 
 Sample::Sample(const Config& cfg, clcuda::Queue q) : Sample(cfg, q, static_cast<unsigned int>(rand())) {}
+
+bool Sample::Serialize(std::ostream* out) {
+  SampleStorage storage;
+  storage.edges.assign(reinterpret_cast<const char*>(edges.data()), edges.size() * sizeof(Edge));
+  storage.nodes_vec.assign(reinterpret_cast<const char*>(nodes_vec.data()), nodes_vec.size() * sizeof(Vertex));
+  storage.seed = seed;
+  return SerializeMessage(out, storage) && ::mcmc::Serialize(out, &dev_edges, &queue) &&
+         ::mcmc::Serialize(out, &dev_nodes, &queue) && neighbor_sampler.Serialize(out);
+}
+
+bool Sample::Parse(std::istream* in) {
+  SampleStorage storage;
+  if (!(ParseMessage(in, &storage) && ::mcmc::Parse(in, &dev_edges, &queue) && ::mcmc::Parse(in, &dev_nodes, &queue) &&
+        neighbor_sampler.Parse(in)))
+    return false;
+  edges.resize(storage.edges.size() / sizeof(Edge));
+  memcpy(edges.data(), storage.edges.data(), edges.size() * sizeof(Edge));
+  nodes_vec.resize(storage.nodes_vec.size() / sizeof(Vertex));
+  memcpy(nodes_vec.data(), storage.nodes_vec.data(), nodes_vec.size() * sizeof(Vertex));
+  seed = storage.seed;
+  return true;
+}
 
 // ------------------------------------------------------------------------------ PhiUpdater
 
@@ -218,6 +247,23 @@ void PhiUpdater::operator()(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex
   }
 }
 
+bool PhiUpdater::Serialize(std::ostream* out) {
+  PhiProperties props;
+  props.count_calls = count_calls_;
+  props.update_phi_time = static_cast<double>(t_update_phi_);
+  props.update_pi_time = static_cast<double>(t_update_pi_);
+  return rand_.Serialize(out) && SerializeMessage(out, props);
+}
+
+bool PhiUpdater::Parse(std::istream* in) {
+  PhiProperties props;
+  if (!(rand_.Parse(in) && ParseMessage(in, &props))) return false;
+  count_calls_ = props.count_calls;
+  t_update_phi_ = static_cast<uint64_t>(props.update_phi_time);
+  t_update_pi_ = static_cast<uint64_t>(props.update_pi_time);
+  return true;
+}
+
 // ----------------------------------------------------------------------------- BetaUpdater
 
 BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& theta,
@@ -245,6 +291,30 @@ void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Fl
                                   0, queue_.stream()),
                "ammsb_update_theta");
   queue_.Finish();
+}
+
+bool BetaUpdater::Serialize(std::ostream* out) {
+  // theta_sum_ (beta.cc:20-28) is recomputed by every launch; the record is produced from theta
+  std::vector<Float> theta(theta_.Count());
+  theta_.Read(queue_, theta.size(), theta.data());
+  VectorStorage sum;
+  sum.storage.resize(theta.size() / 2 * sizeof(Float));
+  for (size_t k = 0; k + 1 < theta.size(); k += 2) {
+    const Float ts = theta[k] + theta[k + 1];
+    memcpy(&sum.storage[k / 2 * sizeof(Float)], &ts, sizeof(Float));
+  }
+  BetaProperties props;
+  props.count_calls = count_calls_;
+  return rand_.Serialize(out) && SerializeMessage(out, sum) && SerializeMessage(out, props);
+}
+
+bool BetaUpdater::Parse(std::istream* in) {
+  VectorStorage sum;
+  BetaProperties props;
+  if (!(rand_.Parse(in) && ParseMessage(in, &sum) && ParseMessage(in, &props))) return false;
+  if (sum.storage.size() != theta_.Count() / 2 * sizeof(Float)) return false;
+  count_calls_ = props.count_calls;
+  return true;
 }
 
 // -------------------------------------------------------------------- PerplexityCalculator
@@ -278,6 +348,19 @@ Float PerplexityCalculator::operator()() {
   double avg = 0.0;  // perplexity.cc:264-268
   if (s.link_cnt + s.nonlink_cnt != 0) avg = (s.link_ll + s.nonlink_ll) / static_cast<double>(s.link_cnt + s.nonlink_cnt);
   return static_cast<Float>(-avg);
+}
+
+bool PerplexityCalculator::Serialize(std::ostream* out) {
+  PerplexityProperties props;
+  props.count_calls = count_calls_;
+  return SerializeMessage(out, props) && ::mcmc::Serialize(out, &ppx_per_edge_, &queue_);
+}
+
+bool PerplexityCalculator::Parse(std::istream* in) {
+  PerplexityProperties props;
+  if (!ParseMessage(in, &props)) return false;
+  count_calls_ = props.count_calls;
+  return ::mcmc::Parse(in, &ppx_per_edge_, &queue_);
 }
 
 }  // namespace mcmc

@@ -322,6 +322,121 @@ class Learner:
         self.time += time.perf_counter() - t1
         return ppx
 
+    # ------------------------------------------------------------------ checkpoint (learner.cc:301-363)
+
+    def _sample_records(self, out, s):
+        """Sample::Serialize (sample.h:62-75) + NeighborSampler::Serialize (sample.h:30-32)."""
+        from . import checkpoint as ck
+        ck.write_message(out, [(1, ck.BYTES, np.ascontiguousarray(s.edges, dtype=np.uint64).tobytes()),
+                               (2, ck.BYTES, np.ascontiguousarray(s.nodes_vec, dtype=np.uint32).tobytes()),
+                               (3, ck.VARINT, s.seed)])
+        ck.write_buffer(out, s.dev_edges)
+        ck.write_buffer(out, s.dev_nodes)
+        ck.write_buffer(out, s.neighbor_sampler.rand.seeds)
+        ck.write_buffer(out, s.neighbor_sampler.GetData())
+
+    def _sample_parse(self, inp, s):
+        from . import checkpoint as ck
+        m = ck.read_message(inp, (1, 2, 3))
+        ck.read_buffer(inp, s.dev_edges)
+        ck.read_buffer(inp, s.dev_nodes)
+        ck.read_buffer(inp, s.neighbor_sampler.rand.seeds)
+        ck.read_buffer(inp, s.neighbor_sampler.GetData())
+        s.edges = np.frombuffer(m[1], dtype=np.uint64).copy()
+        s.nodes_vec = np.frombuffer(m[2], dtype=np.uint32).copy()
+        s.seed = int(m[3])
+        s.n_edges, s.n_nodes = s.edges.size, s.nodes_vec.size
+        s.consumed_valid = False
+
+    def _theta_sum(self):
+        t = self.theta.reshape(-1, 2)
+        return (t[:, 0] + t[:, 1]).contiguous()  # BetaUpdater::GetThetaSum(), beta.cc:20-28
+
+    def Serialize(self, out):
+        """Write the learner state to the binary stream `out` in the reference's record order
+        (learner.cc:316-329): beta, theta, pi, phi, PhiUpdater, BetaUpdater, held-out perplexity,
+        LearnerProperties, Sample[0], Sample[1].  With device sampling a trailing extension record
+        (ignored by the reference's Parse, which stops after the samples) carries the device sampler.
+        Every rank holds the same replicated state; rank 0's file is the checkpoint."""
+        from . import checkpoint as ck
+        two = len(self.samples) == 2
+        if two and self.futures[self.phase] is None:
+            self._launch_sample(self.phase)  # the reference's constructor has it in flight already
+        weight = float(self.futures[self.phase].result()) if two else 0.0  # learner.cc:307-314
+        self.ops.synchronize()
+        ck.write_buffer(out, self.beta)
+        ck.write_buffer(out, self.theta)
+        ck.write_rpm(out, self.pi)
+        ck.write_buffer(out, self.phi)
+        # PhiUpdater::Serialize (phi.cc:765-771)
+        ck.write_buffer(out, self.phiUpdater.rand.seeds)
+        ck.write_message(out, [(1, ck.VARINT, self.phiUpdater.count_calls), (2, ck.FIXED64, 0.0), (3, ck.FIXED64, 0.0)])
+        # BetaUpdater::Serialize (beta.cc:386-397)
+        ck.write_buffer(out, self.betaUpdater.rand.seeds)
+        ck.write_buffer(out, self._theta_sum())  # derived: recomputed by every beta_grads launch
+        ck.write_message(out, [(1, ck.VARINT, self.betaUpdater.count_calls)] + [(i, ck.FIXED64, 0.0) for i in range(2, 7)])
+        # PerplexityCalculatorBase::Serialize (perplexity.cc:276-283)
+        calc = self.heldoutPerplexity
+        ck.write_message(out, [(1, ck.VARINT, calc.count_calls), (2, ck.FIXED64, 0.0), (3, ck.FIXED64, 0.0)])
+        ck.write_buffer(out, calc.ppx_per_edge)
+        ck.write_message(out, [(1, ck.VARINT, self.stepCount), (2, ck.VARINT, int(self.time * 1e9)),
+                               (3, ck.VARINT, int(self.samplingTime * 1e9)), (4, ck.VARINT, self.phase),
+                               (5, ck.FIXED64, weight)])
+        for s in self.samples:
+            self._sample_records(out, s)
+        if self.dev_sampler is not None:
+            import json
+            st = dict(rng=self.dev_sampler.host_rng.bit_generator.state,
+                      sizes=[[s.n_edges, s.n_nodes] for s in self.samples], edges_done=self.edges_done)
+            ck.write_message(out, [(1, ck.BYTES, b"AMMSB-DEVSAMPLER-1"), (2, ck.BYTES, json.dumps(st).encode())])
+            ck.write_buffer(out, self.dev_sampler.rand.seeds)
+        return True
+
+    def Parse(self, inp):
+        """Restore from a stream written by Serialize (or by the reference, for the same Config and
+        buffer sizes).  Size mismatches raise CheckpointError (the reference returns false)."""
+        from . import checkpoint as ck
+        for f in self.futures:
+            if f is not None:
+                f.result()
+        self.ops.synchronize()
+        ck.read_buffer(inp, self.beta)
+        ck.read_buffer(inp, self.theta)
+        ck.read_rpm(inp, self.pi)
+        ck.read_buffer(inp, self.phi)
+        ck.read_buffer(inp, self.phiUpdater.rand.seeds)
+        self.phiUpdater.count_calls = int(ck.read_message(inp, (1, 2, 3))[1])
+        ck.read_buffer(inp, self.betaUpdater.rand.seeds)
+        ck.read_buffer(inp, self._theta_sum())  # size check only
+        self.betaUpdater.count_calls = int(ck.read_message(inp, (1, 2, 3, 4, 5, 6))[1])
+        calc = self.heldoutPerplexity
+        calc.count_calls = int(ck.read_message(inp, (1, 2, 3))[1])
+        ck.read_buffer(inp, calc.ppx_per_edge)
+        props = ck.read_message(inp, (1, 2, 3, 4, 5))
+        self.stepCount = int(props[1])
+        self.time, self.samplingTime = props[2] * 1e-9, props[3] * 1e-9
+        self.phase = int(props[4]) & 1
+        for s in self.samples:
+            self._sample_parse(inp, s)
+        if self.dev_sampler is not None:
+            import json
+            m = ck.read_message(inp, (1, 2))
+            if m[1] != b"AMMSB-DEVSAMPLER-1":
+                raise ck.CheckpointError("checkpoint has no device-sampler record")
+            st = json.loads(m[2].decode())
+            self.dev_sampler.host_rng.bit_generator.state = st["rng"]
+            for s, (ne, nv) in zip(self.samples, st["sizes"]):
+                s.n_edges, s.n_nodes = int(ne), int(nv)
+            self.edges_done = int(st["edges_done"])
+            ck.read_buffer(inp, self.dev_sampler.rand.seeds)
+        self.futures = [None, None]
+        if len(self.samples) == 2:  # learner.cc:348-353
+            f = concurrent.futures.Future()
+            f.set_result(float(np.float32(props[5])))
+            self.futures[self.phase] = f
+        self.ops.synchronize()
+        return True
+
     def drain(self):
         """Wait for the pending background sample and all device work (used before timing / teardown)."""
         for f in self.futures:

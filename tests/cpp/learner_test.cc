@@ -4,7 +4,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
 #include <memory>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "mcmc/data.h"
@@ -78,7 +82,116 @@ static RunResult RunOnce(uint64_t N, const std::vector<mcmc::Edge>& edges, uint3
   return r;
 }
 
-int main() {
+// ---- checkpoint modes (serialize-test.cc:90-134 + cross-language round trip with the Python learner)
+//   learner_test ckpt DIR     build the data set, write DIR/edges.bin; run 40, Serialize -> DIR/cpp.ckpt,
+//                             run 40 -> ppx; fresh learner, Parse, run 40 -> same ppx; write DIR/cpp_ppx.txt
+//   learner_test resume DIR   read DIR/edges.bin + DIR/py.ckpt (written by the Python learner), run 40,
+//                             write DIR/cpp_from_py_ppx.txt
+
+static void FillConfig(mcmc::Config* cfg, uint64_t N) {
+  cfg->N = N;
+  cfg->K = 64;
+  cfg->mini_batch_size = 256;
+  cfg->num_node_sample = 16;
+  cfg->heldout_ratio = 0.05;
+  cfg->alpha = static_cast<mcmc::Float>(1) / cfg->K;
+  cfg->phi_wg_size = cfg->beta_wg_size = cfg->ppx_wg_size = 64;
+  cfg->beta_seed = {44, 45};
+  cfg->neighbor_seed = {56, 57};
+}
+
+static bool Prepare(mcmc::Config* cfg, const std::vector<mcmc::Edge>& e) {
+  cfg->training_edges.clear();
+  cfg->heldout_edges.clear();
+  srand(12345);
+  if (!mcmc::GenerateSetsFromEdges(cfg->N, e, cfg->heldout_ratio, &cfg->training_edges, &cfg->heldout_edges,
+                                   &cfg->training, &cfg->heldout))
+    return false;
+  cfg->trainingGraph.reset(new mcmc::Graph(cfg->N, cfg->training_edges));
+  cfg->heldoutGraph.reset(new mcmc::Graph(cfg->N, cfg->heldout_edges));
+  cfg->E = e.size();
+  return true;
+}
+
+static void WritePpx(const std::string& path, mcmc::Float ppx) {
+  uint32_t bits;
+  memcpy(&bits, &ppx, 4);
+  std::ofstream f(path);
+  f << bits << "\n";
+}
+
+static int CheckpointMode(const std::string& mode, const std::string& dir) {
+  const uint64_t N = 20000;
+  const uint32_t iters = 40;
+  mcmc::Config cfg;
+  FillConfig(&cfg, N);
+  std::vector<mcmc::Edge> e;
+  if (mode == "ckpt") {
+    e = mcmc::GenerateSyntheticGraph(N, 16, 16, 7);
+    bool ok = false;
+    for (int attempt = 0; attempt < 64 && !(ok = Prepare(&cfg, e)); ++attempt) e.resize(e.size() - 40);
+    EXPECT(ok);
+    std::ofstream f(dir + "/edges.bin", std::ios::binary);
+    f.write(reinterpret_cast<const char*>(e.data()), e.size() * sizeof(mcmc::Edge));
+  } else {
+    std::ifstream f(dir + "/edges.bin", std::ios::binary | std::ios::ate);
+    e.resize(static_cast<size_t>(f.tellg()) / sizeof(mcmc::Edge));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(e.data()), e.size() * sizeof(mcmc::Edge));
+    EXPECT(Prepare(&cfg, e));
+  }
+  clcuda::Platform platform((size_t)0);
+  clcuda::Device dev(platform, 0);
+  clcuda::Context context(dev);
+  clcuda::Queue queue(context, dev);
+  if (mode == "ckpt") {
+    std::ostringstream out;
+    mcmc::Float ppx;
+    {
+      mcmc::Learner learner1(cfg, queue);
+      learner1.Run(iters);
+      EXPECT(learner1.Serialize(&out));
+      learner1.Run(iters);
+      ppx = learner1.HeldoutPerplexity();
+    }
+    {
+      std::istringstream in(out.str());
+      mcmc::Learner learner2(cfg, queue);
+      EXPECT(learner2.Parse(&in));
+      learner2.Run(iters);
+      EXPECT(ppx == learner2.HeldoutPerplexity());
+      // a truncated stream and a stream for another shape are refused
+      std::istringstream cut(out.str().substr(0, out.str().size() / 2));
+      mcmc::Learner learner3(cfg, queue);
+      EXPECT(!learner3.Parse(&cut));
+    }
+    {
+      mcmc::Config other;
+      FillConfig(&other, N);
+      other.K = 32;
+      other.alpha = static_cast<mcmc::Float>(1) / other.K;
+      EXPECT(Prepare(&other, e));
+      std::istringstream in(out.str());
+      mcmc::Learner learner4(other, queue);
+      EXPECT(!learner4.Parse(&in));
+    }
+    std::ofstream f(dir + "/cpp.ckpt", std::ios::binary);
+    f << out.str();
+    WritePpx(dir + "/cpp_ppx.txt", ppx);
+    printf("checkpoint: %zu bytes, ppx %.6f\n", out.str().size(), ppx);
+  } else {
+    std::ifstream in(dir + "/py.ckpt", std::ios::binary);
+    mcmc::Learner learner(cfg, queue);
+    EXPECT(learner.Parse(&in));
+    learner.Run(iters);
+    WritePpx(dir + "/cpp_from_py_ppx.txt", learner.HeldoutPerplexity());
+  }
+  printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
+  return fails ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc == 3) return CheckpointMode(argv[1], argv[2]);
   const uint64_t N = 20000;
   const std::vector<mcmc::Edge> edges = mcmc::GenerateSyntheticGraph(N, 16, 16, 7);
   EXPECT(edges.size() > 100000);

@@ -90,6 +90,15 @@ class RowPartitionedMatrix:
     def Rows(self):
         return self.rows
 
+    def Cols(self):
+        return self.cols
+
+    def RowsPerBlock(self):
+        return self.rows
+
+    def Blocks(self):
+        return self.blocks
+
     def host(self):
         return self.blocks[0].numpy().copy()
 

@@ -128,3 +128,77 @@ def test_cpp_dropin_learner(env):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
+
+
+@pytest.mark.parametrize("device_sampling", [False, True])
+def test_checkpoint_end_to_end(env, small_ds, device_sampling):
+    """serialize-test.cc:90-134 on the HIP path: run, Serialize, run == fresh learner, Parse, run."""
+    import io
+    ops, hostlib, learner = env
+    iters = 25
+
+    def cfg():
+        return learner.Config.from_cli_defaults(K=64, mini_batch_size=512, num_node_sample=16, heldout_ratio=0.02,
+                                                phi_wg_size=64, beta_wg_size=64, ppx_wg_size=64,
+                                                device_sampling=device_sampling)
+    out = io.BytesIO()
+    l1 = learner.Learner(cfg(), small_ds)
+    l1.Run(iters)
+    assert l1.Serialize(out)
+    l1.Run(iters)
+    ppx = l1.HeldoutPerplexity()
+    pi1 = l1.pi.host()
+    theta1 = ops.to_numpy(l1.theta)
+    l1.close()
+    l2 = learner.Learner(cfg(), small_ds)
+    assert l2.Parse(io.BytesIO(out.getvalue()))
+    l2.Run(iters)
+    assert l2.HeldoutPerplexity() == ppx
+    assert np.array_equal(l2.pi.host(), pi1) and np.array_equal(ops.to_numpy(l2.theta), theta1)
+    l2.close()
+
+
+def test_checkpoint_cpp_python_round_trip(env, tmp_path):
+    """One stream format for both hosts: the C++ Learner's checkpoint resumes in the Python learner and
+    the other way round, with bit-identical perplexities after 40 more iterations."""
+    import os
+    import subprocess
+    ops, hostlib, learner = env
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mcmc-ammsb-gpu_amd", "learner_test")
+    d = str(tmp_path)
+    out = subprocess.run([exe, "ckpt", d], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    edges = np.fromfile(os.path.join(d, "edges.bin"), dtype=np.uint64)
+    ds = hostlib.Dataset(20000, edges, heldout_ratio=0.05, rand_seed=12345)
+
+    def cfg():  # tests/cpp/learner_test.cc FillConfig
+        return learner.Config.from_cli_defaults(K=64, mini_batch_size=256, num_node_sample=16, heldout_ratio=0.05,
+                                                phi_wg_size=64, beta_wg_size=64, ppx_wg_size=64)
+
+    def bits(path):
+        return int(open(os.path.join(d, path)).read())
+
+    def f32bits(x):
+        return int(np.float32(x).view(np.uint32))
+    l = learner.Learner(cfg(), ds)
+    with open(os.path.join(d, "cpp.ckpt"), "rb") as f:
+        assert l.Parse(f)
+        assert f.read() == b""  # every byte of the C++ stream is consumed
+    l.Run(40)
+    assert f32bits(l.HeldoutPerplexity()) == bits("cpp_ppx.txt")
+    l.close()
+    # the other direction
+    l = learner.Learner(cfg(), ds)
+    l.Run(40)
+    with open(os.path.join(d, "py.ckpt"), "wb") as f:
+        l.Serialize(f)
+    l.Run(40)
+    want = f32bits(l.HeldoutPerplexity())
+    l.close()
+    # byte-level: same state at the same step => same stream, except the wall-clock fields
+    a = open(os.path.join(d, "cpp.ckpt"), "rb").read()
+    b = open(os.path.join(d, "py.ckpt"), "rb").read()
+    assert abs(len(a) - len(b)) <= 64
+    out = subprocess.run([exe, "resume", d], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    assert bits("cpp_from_py_ppx.txt") == want
