@@ -192,6 +192,13 @@ class BetaUpdater {
               const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
   void operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale);
   clcuda::Buffer<Float>& GetGrads() { return grads_; }
+  // device time in ns.  The reference's five stages (beta.h:30-34) are two launches here: theta_sum +
+  // partial gradients + their sum are one call, update_theta + theta->beta normalisation the other.
+  uint64_t ThetaSumTime() const { return 0; }
+  uint64_t GradsPartialTime() const { return t_grads_; }
+  uint64_t GradsSumTime() const { return 0; }
+  uint64_t UpdateThetaTime() const { return t_update_theta_; }
+  uint64_t NormalizeTime() const { return 0; }
   bool Serialize(std::ostream* out);  // beta.cc:386-413
   bool Parse(std::istream* in);
 
@@ -205,6 +212,7 @@ class BetaUpdater {
   random::OpenClRandom rand_;
   uint32_t count_calls_, local_;
   clcuda::Buffer<Float> grads_;
+  uint64_t t_grads_ = 0, t_update_theta_ = 0;
 };
 
 class PerplexityCalculator {
@@ -214,6 +222,8 @@ class PerplexityCalculator {
                        RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Edge>& edges, OpenClSet* edgeSet,
                        const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
   Float operator()();  // returns -average log-likelihood (perplexity.cc:273)
+  uint64_t PerplexityTime() const { return t_ppx_; }  // ns; the four reductions are inside the same launch
+  uint64_t AccumulateTime() const { return 0; }
   bool Serialize(std::ostream* out);  // perplexity.cc:276-293
   bool Parse(std::istream* in);
 
@@ -227,6 +237,7 @@ class PerplexityCalculator {
   clcuda::Buffer<Float> ppx_per_edge_;
   clcuda::Buffer<ammsb_ppx_sums> sums_;
   uint32_t count_calls_, local_;
+  uint64_t t_ppx_ = 0;
 };
 
 }  // namespace mcmc

@@ -133,13 +133,22 @@ bool Learner::Parse(std::istream* in) {
   return true;
 }
 
-void Learner::PrintStats(std::ostream& out) {
+void Learner::PrintStats(std::ostream& out) {  // learner.cc:252-299: same categories, seconds and share of TOTAL
   const double total = time_ / 1.0e9;
-  auto pct = [&](double v) { return total > 0 ? 100 * v / total : 0.0; };
+  auto line = [&](const char* name, uint64_t ns) {
+    out << name << ": " << ns / 1.0e9 << " (%" << (total > 0 ? 100 * (ns / 1.0e9) / total : 0.0) << ")\n";
+  };
   out << "TOTAL    : " << total << "\n";
-  out << "SAMPLING : " << samplingTime_ / 1.0e9 << " (%" << pct(samplingTime_ / 1.0e9) << ")\n";
-  out << "PHI      : " << phiUpdater_.UpdatePhiTime() / 1.0e9 << " (%" << pct(phiUpdater_.UpdatePhiTime() / 1.0e9) << ")\n";
-  out << "PI       : " << phiUpdater_.UpdatePiTime() / 1.0e9 << " (%" << pct(phiUpdater_.UpdatePiTime() / 1.0e9) << ")\n";
+  line("PPX CALC ", heldoutPerplexity_.PerplexityTime());
+  line("PPX ACCUM", heldoutPerplexity_.AccumulateTime());
+  line("SAMPLING ", samplingTime_);
+  line("PHI      ", phiUpdater_.UpdatePhiTime());
+  line("PI       ", phiUpdater_.UpdatePiTime());
+  line("THETA SUM   ", betaUpdater_.ThetaSumTime());
+  line("GRADS PAR   ", betaUpdater_.GradsPartialTime());
+  line("GRADS SUM   ", betaUpdater_.GradsSumTime());
+  line("UPDATE THETA", betaUpdater_.UpdateThetaTime());
+  line("NORM THETA  ", betaUpdater_.NormalizeTime());
 }
 
 void Learner::PrintStats() { PrintStats(std::cerr); }

@@ -282,14 +282,18 @@ BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::B
 
 void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale) {
   ++count_calls_;  // beta.cc:336
+  EventTimer tg(queue_.stream());
   ThrowIfError(ctx_.get(),
                ammsb_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), &trainingSet_->Get(), edges->data(),
                                 num_edges, 0, num_edges, local_, grads_.data(), queue_.stream()),
                "ammsb_beta_grads");
+  t_grads_ += tg.StopNs();
+  EventTimer tu(queue_.stream());
   ThrowIfError(ctx_.get(),
                ammsb_update_theta(ctx_.get(), theta_.data(), beta_.data(), grads_.data(), count_calls_, scale, rand_.Get(),
                                   0, queue_.stream()),
                "ammsb_update_theta");
+  t_update_theta_ += tu.StopNs();
   queue_.Finish();
 }
 
@@ -305,6 +309,8 @@ bool BetaUpdater::Serialize(std::ostream* out) {
   }
   BetaProperties props;
   props.count_calls = count_calls_;
+  props.grads_partial_time = static_cast<double>(t_grads_);
+  props.update_theta_time = static_cast<double>(t_update_theta_);
   return rand_.Serialize(out) && SerializeMessage(out, sum) && SerializeMessage(out, props);
 }
 
@@ -314,6 +320,8 @@ bool BetaUpdater::Parse(std::istream* in) {
   if (!(rand_.Parse(in) && ParseMessage(in, &sum) && ParseMessage(in, &props))) return false;
   if (sum.storage.size() != theta_.Count() / 2 * sizeof(Float)) return false;
   count_calls_ = props.count_calls;
+  t_grads_ = static_cast<uint64_t>(props.grads_partial_time);
+  t_update_theta_ = static_cast<uint64_t>(props.update_theta_time);
   return true;
 }
 
@@ -339,10 +347,12 @@ PerplexityCalculator::PerplexityCalculator(Mode, const Config& cfg, clcuda::Queu
 Float PerplexityCalculator::operator()() {
   ++count_calls_;  // perplexity.cc:252
   const uint32_t H = static_cast<uint32_t>(edges_.Count());
+  EventTimer t(queue_.stream());
   ThrowIfError(ctx_.get(),
                ammsb_perplexity(ctx_.get(), beta_.data(), &pi_->Get(), &edgeSet_->Get(), edges_.data(), H, 0, H,
                                 count_calls_, local_, ppx_per_edge_.data(), sums_.data(), queue_.stream()),
                "ammsb_perplexity");
+  t_ppx_ += t.StopNs();
   ammsb_ppx_sums s;
   sums_.Read(queue_, 1, &s);
   double avg = 0.0;  // perplexity.cc:264-268
@@ -353,6 +363,7 @@ Float PerplexityCalculator::operator()() {
 bool PerplexityCalculator::Serialize(std::ostream* out) {
   PerplexityProperties props;
   props.count_calls = count_calls_;
+  props.ppx_time = static_cast<double>(t_ppx_);
   return SerializeMessage(out, props) && ::mcmc::Serialize(out, &ppx_per_edge_, &queue_);
 }
 
@@ -360,6 +371,7 @@ bool PerplexityCalculator::Parse(std::istream* in) {
   PerplexityProperties props;
   if (!ParseMessage(in, &props)) return false;
   count_calls_ = props.count_calls;
+  t_ppx_ = static_cast<uint64_t>(props.ppx_time);
   return ::mcmc::Parse(in, &ppx_per_edge_, &queue_);
 }
 
