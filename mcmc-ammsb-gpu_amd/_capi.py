@@ -91,6 +91,10 @@ def load(path=None):
     if not os.path.exists(so):
         raise AmmsbError("%s not found: build it with `make -C mcmc-ammsb-gpu_amd/csrc` "
                          "(or __graft_entry__.build()); there is no CPU fallback" % so)
+    # One HIP runtime per process: torch carries its own libamdhip64, and device pointers / streams are
+    # handed from torch to this library.  Loading torch first makes the library bind to that copy; the
+    # other order gives two runtimes that cannot see each other's devices.
+    import torch  # noqa: F401
     lib = C.CDLL(so)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
