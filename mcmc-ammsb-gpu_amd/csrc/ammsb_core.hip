@@ -265,6 +265,68 @@ __global__ __launch_bounds__(64) void sample_neighbors_kernel(ammsb_seed* seeds,
   seeds[gid] = seed;
 }
 
+// Same algorithm with each lane's open-addressing table held in LDS (column `lane` of a
+// [capacity][64] array: one bank per lane whatever slot it probes).  The global-memory form above
+// chains ~2n dependent round trips to HBM per node; here the only global traffic is the node id, the
+// stream state and the two coalesced result arrays (the table image is still written out:
+// NeighborSampler::GetHash() exposes it).  Results are identical by construction.
+__global__ __launch_bounds__(64) void sample_neighbors_lds_kernel(ammsb_seed* seeds, const uint32_t* nodes,
+                                                                   uint32_t n_nodes, uint32_t N, uint32_t n,
+                                                                   uint32_t gsize, uint32_t* table, uint32_t* packed) {
+  extern __shared__ uint32_t lds[];  // [capacity][64]
+  const uint32_t lane = threadIdx.x;
+  const uint32_t gid = blockIdx.x * 64 + lane;
+  const uint32_t capacity = 2 * n;
+  const bool owner = gid < gsize && gid < n_nodes;
+  ammsb_seed seed = owner ? seeds[gid] : ammsb_seed{0, 0};
+  const uint32_t max_id = N - 1;
+  for (uint32_t base = blockIdx.x * 64; base < n_nodes; base += gsize) {  // uniform across the block
+    const uint32_t i = base + lane;
+    const bool on = owner && i < n_nodes;
+    const uint32_t live = min(64u, min(n_nodes - base, gsize - blockIdx.x * 64));  // lanes with a node this round
+    for (uint32_t j = 0; j < capacity; ++j) lds[j * 64 + lane] = N;
+    if (on) {
+      const uint32_t node = nodes[i];
+      for (uint32_t j = 0; j < n; ++j) {
+        uint32_t r, val;
+        do {
+          do {
+            r = (uint32_t)(rng_next(seed) % (uint64_t)(max_id + 1));
+          } while (r == node);
+          const uint32_t l1 = (r ^ 553105253u) % capacity;
+          const uint32_t l2 = 1u + (capacity << 1);
+          for (uint32_t t = 0;; ++t) {
+            const uint32_t offset = (l1 + t * l2) % capacity;
+            val = lds[offset * 64 + lane];
+            if (val == r) break;
+            if (val == max_id + 1) {
+              lds[offset * 64 + lane] = r;
+              break;
+            }
+          }
+        } while (val == r);
+      }
+    }
+    __syncthreads();
+    // table image: `live` consecutive rows of `capacity` words
+    uint32_t* tout = table + (uint64_t)base * capacity;
+    for (uint32_t x = lane; x < live * capacity; x += 64) tout[x] = lds[(x % capacity) * 64 + x / capacity];
+    __syncthreads();
+    if (on) {  // compact in place: count <= j, so the write never overtakes the read
+      uint32_t count = 0;
+      for (uint32_t j = 0; j < capacity && count < n; ++j) {
+        const uint32_t v = lds[j * 64 + lane];
+        if (v != N) lds[(count++) * 64 + lane] = v;
+      }
+    }
+    __syncthreads();
+    uint32_t* pout = packed + (uint64_t)base * n;
+    for (uint32_t x = lane; x < live * n; x += 64) pout[x] = lds[(x % n) * 64 + x / n];
+    __syncthreads();
+  }
+  if (owner) seeds[gid] = seed;
+}
+
 extern "C" int ammsb_sample_neighbors(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes,
                                       uint32_t wg, uint32_t* table, uint32_t* packed, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && seeds && nodes && table && packed, "null argument");
@@ -276,8 +338,13 @@ extern "C" int ammsb_sample_neighbors(ammsb_ctx* ctx, ammsb_seed* seeds, const u
   const uint32_t maxg = AMMSB_MAX_GROUPS / wg;
   if (groups > maxg) groups = maxg;
   const uint32_t gsize = groups * wg;
-  sample_neighbors_kernel<<<div_up(gsize, 64), 64, 0, as_stream(stream)>>>(
-      seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed);
+  const size_t lds_bytes = (size_t)2 * n * 64 * sizeof(uint32_t);
+  if (lds_bytes <= 64 * 1024)
+    sample_neighbors_lds_kernel<<<div_up(gsize, 64), 64, lds_bytes, as_stream(stream)>>>(
+        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed);
+  else
+    sample_neighbors_kernel<<<div_up(gsize, 64), 64, 0, as_stream(stream)>>>(
+        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

@@ -178,6 +178,30 @@ __device__ __forceinline__ float div_with_rcp(float x, float d, float r) {
   return __builtin_fmaf(e2, r, q1);
 }
 
+// Three-instruction form (Markstein's final step): with y = RN(1/d) -- the correctly rounded reciprocal,
+// obtained here from one IEEE `1.0f / d` per divisor -- and q0 = RN(x * y),
+//     rem = fma(-d, q0, x) is exact and fma(rem, y, q0) = RN(x / d)
+// (P. Markstein, "Computation of elementary functions on the IBM RISC System/6000", 1990, Thm 4-5; the
+// same no-underflow conditions as above).  A Newton-refined v_rcp_f32 is NOT always RN(1/d) (33 of the
+// 3 * 2^23 seed cases miss, tests/cpp/div_check.c), hence the real division for y.  div_check.c also
+// runs the three-instruction tail against `/` on 5e8 operand pairs without a mismatch.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float exact_rcp(float d) { return 1.0f / d; }
+
+__device__ __forceinline__ float div_exact3(float x, float d, float y) {
+  const float q0 = x * y;
+  const float rem = __builtin_fmaf(-d, q0, x);
+  return __builtin_fmaf(rem, y, q0);
+}
+
+// two quotients per instruction (v_pk_mul_f32 / v_pk_fma_f32 round each half like the scalar forms)
+__device__ __forceinline__ f32x2 div_exact3(f32x2 x, f32x2 d, f32x2 y) {
+  const f32x2 q0 = x * y;
+  const f32x2 rem = __builtin_elementwise_fma(-d, q0, x);
+  return __builtin_elementwise_fma(rem, y, q0);
+}
+
 // ------------------------------------------------------------------------------------ cuckoo
 // Set_HasEdge, mcmc/cuckoo.cc:27-69.  Both 32-byte bins are fetched at once (two independent
 // 2 x 16 B loads each) instead of the reference's dependent second probe.

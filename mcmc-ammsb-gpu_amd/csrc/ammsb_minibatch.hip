@@ -3,13 +3,13 @@
 // The reference draws every mini-batch on one host thread (mcmc/sample.cc:249-303: rand_r, an
 // std::unordered_set<Edge> and two host cuckoo probes per candidate, then learner.cc:162-173 builds
 // the node list through another unordered_set).  At m = 65536 that is ~10 ms per batch, four times
-// the device work it feeds.  Here the non-link half runs as four small kernels:
+// the device work it feeds.  Here the non-link half runs as three small kernels:
 //   1. candidate j draws v_j from its own xorshift128+ stream, checks v_j != u and both cuckoo sets,
 //      and registers (v_j -> min j) in an open-addressing table (atomicCAS / atomicMin);
 //   2. a candidate is kept iff it is valid and the table names it as the first occurrence of v_j;
 //      per-block keep counts;
-//   3. one block scans the block counts;
-//   4. kept candidates are written in candidate order (first m of them), then the node list.
+//   3. every block sums the counts of the blocks before it and writes its kept candidates in candidate
+//      order (first m of them), then the node list.
 // The result is a deterministic function of (stream states, u, sets).
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
@@ -125,35 +125,24 @@ __global__ __launch_bounds__(MB_BLOCK) void mb_count_kernel(MbWork w) {
   if (threadIdx.x == 0) w.blk[blockIdx.x] = total;
 }
 
-// exclusive scan of the per-block counts by one block (nb <= a few hundred)
-__global__ __launch_bounds__(1024) void mb_scan_kernel(MbWork w, uint32_t nb, uint32_t* count_out) {
-  __shared__ uint32_t s[1024];
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < nb; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t x = i < nb ? w.blk[i] : 0;
-    s[threadIdx.x] = x;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-      const uint32_t t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nb) w.blk[i] = carry + s[threadIdx.x] - x;
-    const uint32_t tot = s[1023];
-    __syncthreads();
-    carry += tot;
-  }
-  if (threadIdx.x == 0) count_out[0] = carry;
-}
-
+// Each block adds up the counts of the blocks before it (a few hundred at most) instead of waiting
+// for a separate scan launch: a lone scan block cannot get a CU while update_phi fills the chip, which
+// used to park the whole sampling chain behind it.
 __global__ __launch_bounds__(MB_BLOCK) void mb_write_kernel(MbWork w, uint32_t u, uint32_t m, uint64_t* edges,
-                                                             uint32_t* nodes) {
+                                                             uint32_t* nodes, uint32_t* count_out) {
+  __shared__ uint32_t part[MB_BLOCK / 64];
+  uint32_t before = 0;
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += MB_BLOCK) before += w.blk[i];
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_down(before, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = before;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int i = 0; i < MB_BLOCK / 64; ++i) base += part[i];
   const uint32_t j = blockIdx.x * MB_BLOCK + threadIdx.x;
   const bool keep = mb_keep(w, j);
   uint32_t total;
-  const uint32_t rank = w.blk[blockIdx.x] + block_exclusive_scan(keep ? 1u : 0u, &total);
+  const uint32_t rank = base + block_exclusive_scan(keep ? 1u : 0u, &total);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count_out[0] = base + total;
   if (keep && rank < m) {
     const uint32_t v = w.cand[j] & 0x7fffffffu;
     edges[rank] = make_edge(u, v);
@@ -228,8 +217,7 @@ extern "C" int ammsb_minibatch_nonlink(ammsb_ctx* ctx, ammsb_seed* seeds, uint32
   mb_draw_kernel<<<nb, MB_BLOCK, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, *training_set,
                                          heldout_set ? *heldout_set : none, heldout_set ? 1 : 0);
   mb_count_kernel<<<nb, MB_BLOCK, 0, s>>>(w);
-  mb_scan_kernel<<<1, 1024, 0, s>>>(w, nb, count_out);
-  mb_write_kernel<<<nb, MB_BLOCK, 0, s>>>(w, u, m, edges_out, nodes_out);
+  mb_write_kernel<<<nb, MB_BLOCK, 0, s>>>(w, u, m, edges_out, nodes_out, count_out);
   mb_fill_kernel<<<64, 256, 0, s>>>(m, count_out, edges_out, nodes_out);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;

@@ -21,6 +21,8 @@
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
 
+#include <type_traits>
+
 using namespace ammsb;
 
 namespace {
@@ -244,14 +246,15 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 template <int KPT>
-__global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
   using Grp = Group<64>;
   constexpr int K = 64 * KPT;
   constexpr int PIECES = KPT / 4;  // 1 KiB LDS-DMA pieces per row
-  extern __shared__ __align__(16) char smem[];  // [2][K] floats (ring) then [n] u32 (neighbour id | link bit)
+  extern __shared__ __align__(16) char smem[];  // [2][K] ring, [K] normals, [n] u32 (neighbour id | link bit)
   __shared__ ZigTables zig;
   float* ring = reinterpret_cast<float*>(smem);
-  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + 2 * K * sizeof(float));
+  float* s_noise = ring + 2 * K;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + 3 * K * sizeof(float));
 
   const int l = threadIdx.x;
   const uint32_t g = a.group_begin + blockIdx.x;
@@ -260,13 +263,15 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
   const float EPS = a.epsilon;
   if (a.noise_on) zig_load(&zig);
 
-  float bf[KPT];
+  constexpr int HP = KPT / 2;  // column pairs per lane: pair p = columns l + 64 (2p), l + 64 (2p + 1)
+  f32x2 bf[HP];
   bool beta_safe = true;
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const float b = a.beta[2 * (l + 64 * j) + 1];
-    bf[j] = b - EPS;
-    beta_safe = beta_safe && in_range(b, EPS, kBetaHi);
+  for (int p = 0; p < HP; ++p) {
+    const float b0 = a.beta[2 * (l + 128 * p) + 1];
+    const float b1 = a.beta[2 * (l + 128 * p + 64) + 1];
+    bf[p] = f32x2{b0 - EPS, b1 - EPS};
+    beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
   }
   ammsb_seed rs = {0, 0};
   if (a.noise_on) rs = a.seeds[(uint64_t)g * 64 + l];
@@ -295,17 +300,17 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
     const float phi_sum = a.phi_sum[node];
     const float inv_phi_sum = 1.0f / phi_sum;
     const float* row_a = rpm_row(a.pi, node);
-    float pi_a[KPT], grads[KPT], rden[KPT];
+    f32x2 pi_a[HP], grads[HP], rden[HP];
     bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) pi_a[j] = row_a[l + 64 * j];
+    for (int p = 0; p < HP; ++p) pi_a[p] = f32x2{row_a[l + 128 * p], row_a[l + 128 * p + 64]};
     request(0, 0);  // the first row's flight overlaps the per-node set-up below
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      grads[j] = 0.0f;
-      const float den = pi_a[j] * phi_sum;
-      rden[j] = refined_rcp(den);
-      node_safe = node_safe && in_range(den, kDenLo, kDenHi);
+    for (int p = 0; p < HP; ++p) {
+      grads[p] = f32x2{0.0f, 0.0f};
+      const f32x2 den = pi_a[p] * phi_sum;
+      rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
+      node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
     }
 
     for (uint32_t q = 0; q < n; ++q) {
@@ -315,6 +320,9 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (q + 1 < n) {
         request(q + 1, slot ^ 1);
+        // one of the node's K normals per iteration, drawn while row q is still on its way (stream order is
+        // the ascending column order of the SGLD step below)
+        if (a.noise_on && q < (uint32_t)KPT) s_noise[l + 64 * q] = rng_normal(rs, &zig);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // row q landed, row q+1 in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -323,46 +331,58 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
       y = __builtin_amdgcn_readfirstlane((int)y) != 0;
       const float e = y ? EPS : 1.0f - EPS;
 
-      // pass 1 (phi.cc:241-253): probs[] in place of the row, lane partial in ascending column order
+      // pass 1 (phi.cc:241-253): probs[] in place of the row, lane partial in ascending column order.
+      // pin * (EPS - beta) + e == e - pin * (beta - EPS) bit for bit; the two wave-uniform cases are separate
+      // code so that the sign rides on the packed add's source modifier.
       float partial = 0.0f, lo = 1.0f;
+      auto pass1 = [&](auto link) {
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const float tt0 = row[l + 64 * j] * bf[j];
-        const float tt = y ? tt0 + e : e - tt0;  // pin * (EPS - beta) + e == e - pin * (beta - EPS), bit for bit
-        const float pr = pi_a[j] * tt;
-        row[l + 64 * j] = pr;
-        partial += pr;
-        lo = fminf(lo, fabsf(pr));
-      }
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 pin = f32x2{row[l + 128 * p], row[l + 128 * p + 64]};
+          const f32x2 tt0 = pin * bf[p];
+          const f32x2 tt = decltype(link)::value ? tt0 + e : e - tt0;
+          const f32x2 pr = pi_a[p] * tt;
+          row[l + 128 * p] = pr.x;
+          row[l + 128 * p + 64] = pr.y;
+          partial += pr.x;
+          partial += pr.y;
+          lo = fminf(fminf(lo, fabsf(pr.x)), fabsf(pr.y));
+        }
+      };
+      if (y) pass1(std::true_type{});
+      else pass1(std::false_type{});
       const float probs_sum = Grp::sum(partial, (float*)nullptr, phase);  // phi.cc:254-257
 
       // pass 2 (phi.cc:259-263): grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
       if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
-        const float rps = refined_rcp(probs_sum);
+        const float rps = exact_rcp(probs_sum);
         float ps = phi_sum;
         asm volatile("" : "+v"(ps));  // keeps pi_a * phi_sum from being hoisted into KPT more registers
+        const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-          float qv = div_with_rcp(row[l + 64 * j], probs_sum, rps);
-          qv = div_with_rcp(qv, pi_a[j] * ps, rden[j]);
-          grads[j] += qv - inv_phi_sum;
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 pr = f32x2{row[l + 128 * p], row[l + 128 * p + 64]};
+          f32x2 qv = div_exact3(pr, psum2, rps2);
+          qv = div_exact3(qv, pi_a[p] * ps, rden[p]);
+          grads[p] += qv - inv_phi_sum;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-          float qv = row[l + 64 * j] / probs_sum;
-          qv = qv / (pi_a[j] * phi_sum);
-          grads[j] += qv - inv_phi_sum;
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 den = pi_a[p] * phi_sum;
+          float q0 = row[l + 128 * p] / probs_sum;
+          float q1 = row[l + 128 * p + 64] / probs_sum;
+          q0 = q0 / den.x;
+          q1 = q1 / den.y;
+          grads[p] += f32x2{q0 - inv_phi_sum, q1 - inv_phi_sum};
         }
       }
     }
 
-    // The ring is idle now: slot 0 receives this node's K normals.  One rolled loop (a single copy of
-    // the ziggurat code with its binary64 tail, dynamic LDS index) instead of KPT inlined copies.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // normals the loop did not get to (n - 1 < KPT): one rolled loop, a single copy of the ziggurat code
     if (a.noise_on) {
 #pragma unroll 1
-      for (int j = 0; j < KPT; ++j) ring[l + 64 * j] = rng_normal(rs, &zig);
+      for (uint32_t j = n > 0 ? n - 1 : 0; j < (uint32_t)KPT; ++j) s_noise[l + 64 * j] = rng_normal(rs, &zig);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -370,19 +390,21 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
     float* out = a.phi_vec + i * K;
     const float half = a.eps_t / 2;
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const float noise = a.noise_on ? ring[l + 64 * j] : 1.0f;
-      const float phi_k = pi_a[j] * phi_sum;
-      const float ng = a.Nn * grads[j];
-      float in = a.alpha - phi_k;
+    for (int p = 0; p < HP; ++p) {
+      const f32x2 noise = a.noise_on ? f32x2{s_noise[l + 128 * p], s_noise[l + 128 * p + 64]} : f32x2{1.0f, 1.0f};
+      const f32x2 phi_k = pi_a[p] * phi_sum;
+      const f32x2 ng = grads[p] * a.Nn;
+      f32x2 in = a.alpha - phi_k;
       in = in + ng;
-      const float drift = half * in;
-      const float aa = phi_k + drift;
-      const float ep = a.eps_t * phi_k;
-      const float sq = sqrtf(ep);
-      const float bb = sq * noise;
-      const float v = fabsf(aa + bb);
-      out[l + 64 * j] = v > 1e-24f ? v : 1e-24f;
+      const f32x2 drift = in * half;
+      const f32x2 aa = phi_k + drift;
+      const f32x2 ep = phi_k * a.eps_t;
+      const f32x2 sq = f32x2{sqrtf(ep.x), sqrtf(ep.y)};
+      const f32x2 bb = sq * noise;
+      const f32x2 s2 = aa + bb;
+      const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
+      out[l + 128 * p] = v0 > 1e-24f ? v0 : 1e-24f;
+      out[l + 128 * p + 64] = v1 > 1e-24f ? v1 : 1e-24f;
     }
   }
   if (a.noise_on) a.seeds[(uint64_t)g * 64 + l] = rs;
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(64) void update_phi_lds_kernel(const PhiArgs a) {
 
 template <int KPT>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
-  const size_t lds = 2 * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  const size_t lds = 3 * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
   update_phi_lds_kernel<KPT><<<n_groups, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
