@@ -311,6 +311,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
       const f32x2 den = pi_a[p] * phi_sum;
       rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
       node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
+      // sqrt(eps_t * phi_k) of the SGLD step does not depend on the gradient: computed here, under the first
+      // row's latency, and parked in the noise slot, where the loop multiplies the normal in
+      const f32x2 ep = den * a.eps_t;
+      s_noise[l + 128 * p] = sqrtf(ep.x);
+      s_noise[l + 128 * p + 64] = sqrtf(ep.y);
     }
 
     for (uint32_t q = 0; q < n; ++q) {
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
         request(q + 1, slot ^ 1);
         // one of the node's K normals per iteration, drawn while row q is still on its way (stream order is
         // the ascending column order of the SGLD step below)
-        if (a.noise_on && q < (uint32_t)KPT) s_noise[l + 64 * q] = rng_normal(rs, &zig);
+        if (a.noise_on && q < (uint32_t)KPT) s_noise[l + 64 * q] = s_noise[l + 64 * q] * rng_normal(rs, &zig);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // row q landed, row q+1 in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
     // normals the loop did not get to (n - 1 < KPT): one rolled loop, a single copy of the ziggurat code
     if (a.noise_on) {
 #pragma unroll 1
-      for (uint32_t j = n > 0 ? n - 1 : 0; j < (uint32_t)KPT; ++j) s_noise[l + 64 * j] = rng_normal(rs, &zig);
+      for (uint32_t j = n > 0 ? n - 1 : 0; j < (uint32_t)KPT; ++j)
+        s_noise[l + 64 * j] = s_noise[l + 64 * j] * rng_normal(rs, &zig);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -391,16 +397,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
     const float half = a.eps_t / 2;
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
-      const f32x2 noise = a.noise_on ? f32x2{s_noise[l + 128 * p], s_noise[l + 128 * p + 64]} : f32x2{1.0f, 1.0f};
+      const f32x2 bb = f32x2{s_noise[l + 128 * p], s_noise[l + 128 * p + 64]};  // sqrt(eps_t * phi_k) * noise
       const f32x2 phi_k = pi_a[p] * phi_sum;
       const f32x2 ng = grads[p] * a.Nn;
       f32x2 in = a.alpha - phi_k;
       in = in + ng;
       const f32x2 drift = in * half;
       const f32x2 aa = phi_k + drift;
-      const f32x2 ep = phi_k * a.eps_t;
-      const f32x2 sq = f32x2{sqrtf(ep.x), sqrtf(ep.y)};
-      const f32x2 bb = sq * noise;
       const f32x2 s2 = aa + bb;
       const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
       out[l + 128 * p] = v0 > 1e-24f ? v0 : 1e-24f;
