@@ -142,7 +142,7 @@ def main():
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.01, rand_seed=1)
     cfg = Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, strategy="Node",
                                    phi_wg_size=pick_wg(K, args.phi_wg, 16),   # K=1024 -> 64: the LDS-streamed kernel
-                                   beta_wg_size=pick_wg(K, args.beta_wg, 8),  # K=1024 -> 128
+                                   beta_wg_size=pick_wg(K, args.beta_wg, 16),  # K=1024 -> 64: the LDS-streamed kernel
                                    ppx_wg_size=pick_wg(K, args.ppx_wg, 16),   # K=1024 -> 64
                                    device_sampling=not args.host_sampling)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)

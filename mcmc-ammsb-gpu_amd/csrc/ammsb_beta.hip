@@ -187,6 +187,186 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-streamed form for L = 64 and K = 64 * KPT (KPT in {4, 8, 16}), the shape of ammsb_phi.hip's
+// update_phi_lds_kernel: one wave per slot, so both WG_SUMs are pure cross-lane reductions (no LDS
+// exchange, no barrier), and the pi rows of the next three edges arrive by LDS-DMA in a four-slot ring while
+// the current edge is being reduced.  probs[] overwrites the row in place.  Same arithmetic and
+// the same operation order as the register kernel at L = 64.
+
+typedef __attribute__((address_space(3))) void beta_lds_void_t;
+typedef const __attribute__((address_space(1))) void beta_glb_void_t;
+
+template <int KPT>
+__global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
+  using Grp = Group<64>;
+  constexpr int K = 64 * KPT, HP = KPT / 2, PIECES = KPT / 4;
+  constexpr uint32_t D = 4;  // ring depth: edge t is reduced while the rows of t+1 .. t+3 are in flight
+  extern __shared__ __align__(16) char smem[];  // [D][K] floats: row of the edge's second end point, then probs
+  float* ring = reinterpret_cast<float*>(smem);
+  const int l = threadIdx.x;
+  const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks
+  const float EPS = a.epsilon;
+
+  f32x2 bk[HP], d0n[HP], d1l[HP], noo[HP];
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    float c[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t k = l + 128 * p + 64 * h;
+      const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
+      const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
+      if (gs == 0) a.theta_sum[k] = ts;
+      const float oo = 1.0f / ts;
+      c[h][0] = a.beta[2 * k + 1];
+      c[h][1] = 1.0f / t0 - oo;
+      c[h][2] = 1.0f / t1 - oo;
+      c[h][3] = 0.0f - oo;
+    }
+    bk[p] = f32x2{c[0][0], c[1][0]};
+    d0n[p] = f32x2{c[0][1], c[1][1]};
+    d1l[p] = f32x2{c[0][2], c[1][2]};
+    noo[p] = f32x2{c[0][3], c[1][3]};
+  }
+  f32x2 acc0[HP], acc1[HP];
+#pragma unroll
+  for (int p = 0; p < HP; ++p) acc0[p] = acc1[p] = f32x2{0.0f, 0.0f};
+
+  // edges of this slot: e(t) = edge_begin + gs + t * P, t < trips
+  const uint32_t n_edges = a.edge_end - a.edge_begin;
+  const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // wave-uniform
+  int phase = 0;
+
+  // keys and link bits: lane i holds trip tb + i (and tb + 64 + i in the second window), probed one
+  // whole window ahead -- see the register kernel
+  auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
+    const bool ok = tb + l < trips;
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + l) * a.P;
+    const unsigned long long edge = a.edges[ok ? e : a.edge_begin];
+    const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
+    *ymask = __ballot(set_has(a.set, make_edge(u, v)));
+    return edge;
+  };
+  uint32_t tb = 0;
+  unsigned long long ym = 0, ym_next = 0;
+  unsigned long long kv = load_keys(0, &ym), kv_next = load_keys(64, &ym_next);
+
+  auto key_of = [&](uint32_t t, bool* y) -> unsigned long long {
+    const uint32_t rel = t - tb;  // 0 .. 127 by construction
+    const bool first = rel < 64u;
+    const uint32_t src = first ? rel : rel - 64u;
+    const unsigned long long edge = first ? __shfl(kv, (int)src, 64) : __shfl(kv_next, (int)src, 64);
+    *y = (((first ? ym : ym_next) >> src) & 1ull) != 0;
+    return edge;
+  };
+  // the row of the second end point goes through the ring; the first end point is shared by every edge of
+  // a mini-batch of the node strategies (sample.cc:249-303), so its row stays in registers until it changes
+  auto request = [&](uint32_t t) {
+    bool y;
+    const unsigned long long edge = key_of(t, &y);
+    const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)(edge & 0xffffffffu));
+    const float* rb = rpm_row(a.pi, v) + 4 * l;
+    char* dst = smem + (t % D) * (K * sizeof(float));
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      __builtin_amdgcn_global_load_lds((beta_glb_void_t*)(rb + 256 * p), (beta_lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+  };
+
+  f32x2 pa[HP];
+  uint32_t cur_u = 0xffffffffu;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) pa[p] = f32x2{0.0f, 0.0f};
+
+  for (uint32_t t = 0; t < D - 1 && t < trips; ++t) request(t);
+  for (uint32_t t = 0; t < trips; ++t) {
+    float* row_b = ring + (t % D) * K;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot (t - 1) % D has been read for the last time
+    if (t + D - 1 < trips) {
+      if (t + D - 1 >= tb + 128) {  // the look-ahead leaves the two key windows: slide them (t >= tb + 64 here)
+        kv = kv_next;
+        ym = ym_next;
+        tb += 64;
+        kv_next = load_keys(tb + 64, &ym_next);
+      }
+      request(t + D - 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PIECES) : "memory");  // row t landed, t+1 .. t+3 in flight
+    } else {
+      const uint32_t ahead = trips - 1 - t;  // 0 .. D-2 rows still in flight behind row t
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bool y;
+    const unsigned long long edge = key_of(t, &y);
+    y = __builtin_amdgcn_readfirstlane((int)y) != 0;
+    const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(edge >> 32));
+    if (u != cur_u) {
+      const float* ra = rpm_row(a.pi, u);
+#pragma unroll
+      for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[l + 128 * p], ra[l + 128 * p + 64]};
+      cur_u = u;
+    }
+
+    // CALC_PROBS, beta.cc:145-160
+    float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      const f32x2 pb = f32x2{row_b[l + 128 * p], row_b[l + 128 * p + 64]};
+      const f32x2 f = pa[p] * pb;
+      scratch += f.x;
+      scratch += f.y;
+      const f32x2 pr = (y ? bk[p] : 1.0f - bk[p]) * f;
+      row_b[l + 128 * p] = pr.x;
+      row_b[l + 128 * p + 64] = pr.y;
+      ppart += pr.x;
+      ppart += pr.y;
+      const float m0 = fabsf(pr.x), m1 = fabsf(pr.y);
+      lo = fminf(fminf(lo, m0 == 0.0f ? 1.0f : m0), m1 == 0.0f ? 1.0f : m1);  // an exact zero divides exactly
+    }
+    const float pi_sum = Grp::sum(scratch, (float*)nullptr, phase);  // beta.cc:209-213
+    float probs_sum = Grp::sum(ppart, (float*)nullptr, phase);       // beta.cc:214-217
+    const float w = y ? EPS : (1.0f - EPS);
+    const float prob_0 = w * (1.0f - pi_sum);
+    probs_sum += prob_0;
+
+    // CALC_GRADS, beta.cc:161-171
+    if (lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+      const float rps = exact_rcp(probs_sum);
+      const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        const f32x2 pr = f32x2{row_b[l + 128 * p], row_b[l + 128 * p + 64]};
+        const f32x2 f = div_exact3(pr, psum2, rps2);
+        acc0[p] += f * (y ? noo[p] : d0n[p]);
+        acc1[p] += f * (y ? d1l[p] : noo[p]);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        const f32x2 f = f32x2{row_b[l + 128 * p] / probs_sum, row_b[l + 128 * p + 64] / probs_sum};
+        acc0[p] += f * (y ? noo[p] : d0n[p]);
+        acc1[p] += f * (y ? d1l[p] : noo[p]);
+      }
+    }
+  }
+
+  float* out = a.partials + (uint64_t)gs * 2 * K;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    *reinterpret_cast<float2*>(out + 2 * (l + 128 * p)) = make_float2(acc0[p].x, acc1[p].x);
+    *reinterpret_cast<float2*>(out + 2 * (l + 128 * p + 64)) = make_float2(acc0[p].y, acc1[p].y);
+  }
+}
+
+template <int KPT>
+int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
+  const size_t lds = 4 * sizeof(float) * 64 * KPT;
+  beta_grads_lds_kernel<KPT><<<a.P, 64, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 // sum_grads: grads[c] = sum over the P partial rows in a fixed order.  16 columns x 16 row-lanes per
 // block (2K/16 blocks, so the whole chip takes part): row-lane r adds rows r, r+16, ... ascending,
 // then the 16 lane sums are added by the halving tree r += r+8, +4, +2, +1.
@@ -205,6 +385,39 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials
     __syncthreads();
   }
   if (r == 0 && c < cols) out[c] = red[0][cl];
+}
+
+// The same reduction for cols % 8 == 0 with wide loads: a block owns 8 columns (two float4 lanes) and
+// 128 row-lanes; row-lane r adds rows r, r + 128, ... ascending (all loads independent, in flight
+// together), then the halving tree r += r + 64, ..., + 1.  2K/8 blocks.
+__global__ __launch_bounds__(256) void sum_partials8_kernel(const float* partials, uint32_t P, uint32_t cols,
+                                                             float* out) {
+  __shared__ float4 red[128][2];
+  const uint32_t h = threadIdx.x & 1, r = threadIdx.x >> 1;
+  const uint32_t c = blockIdx.x * 8 + 4 * h;
+  float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (uint32_t p = r; p < P; p += 128) {
+    const float4 v = *reinterpret_cast<const float4*>(partials + (uint64_t)p * cols + c);
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  red[r][h] = s;
+  __syncthreads();
+  for (uint32_t half = 64; half > 0; half >>= 1) {
+    if (r < half) {
+      float4 x = red[r][h];
+      const float4 y = red[r + half][h];
+      x.x += y.x;
+      x.y += y.y;
+      x.z += y.z;
+      x.w += y.w;
+      red[r][h] = x;
+    }
+    __syncthreads();
+  }
+  if (r == 0) *reinterpret_cast<float4*>(out + c) = red[0][h];
 }
 
 // update_theta (beta.cc:51-82) + beta = pair-normalised theta (beta.cc:376-383; Normalizer slice 2,
@@ -339,11 +552,28 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
   if (want < 64) want = 64;
   if (want > ctx->max_partials) want = ctx->max_partials;
   a.P = span < want ? span : want;
-  AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT16(kpt, {
-                         int rc = launch_grads<L_, KPT_>(ctx, a, s);
-                         if (rc) return rc;
-                       }));
-  sum_partials_kernel<<<(2 * K + 15) / 16, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
+  static const bool force_reg = [] {
+    const char* f = getenv("AMMSB_BETA_FORM");
+    return f && f[0] == 'r';
+  }();
+  if (wg == 64 && !force_reg && K == 64u * (uint32_t)kpt && kpt >= 4 && pi->num_cols % 4 == 0) {
+    int rc = AMMSB_OK;
+    switch (kpt) {
+      case 4: rc = launch_grads_lds<4>(ctx, a, s); break;
+      case 8: rc = launch_grads_lds<8>(ctx, a, s); break;
+      default: rc = launch_grads_lds<16>(ctx, a, s); break;
+    }
+    if (rc) return rc;
+  } else {
+    AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT16(kpt, {
+                           int rc = launch_grads<L_, KPT_>(ctx, a, s);
+                           if (rc) return rc;
+                         }));
+  }
+  if ((2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0)
+    sum_partials8_kernel<<<2 * K / 8, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
+  else
+    sum_partials_kernel<<<(2 * K + 15) / 16, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

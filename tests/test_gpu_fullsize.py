@@ -117,7 +117,8 @@ def test_c3_update_phi_and_pi(orc, big):
     assert torch.equal(part.rand.seeds, upd.rand.seeds)
 
 
-def test_c3_beta_and_perplexity(orc, big):
+@pytest.mark.parametrize("beta_wg", [64, 128])  # 64: LDS-streamed kernel, 128: register kernel
+def test_c3_beta_and_perplexity(orc, big, beta_wg):
     b = big
     ops, ctx, torch, rng = b["ops"], b["ctx"], b["torch"], b["rng"]
     N, K, m = b["N"], b["K"], b["m"]
@@ -131,9 +132,9 @@ def test_c3_beta_and_perplexity(orc, big):
     vv = vv[vv != uu]
     mb = np.concatenate([(np.minimum(uu, vv) << np.uint64(32)) | np.maximum(uu, vv), b["edges"][:m - vv.size + 64]])[:m]
     dev = ctx.from_numpy(mb)
-    bu = ops.BetaUpdater(ctx, b["theta"].clone(), b["beta"].clone(), b["pi"], b["dset"], (44, 45), 128)
+    bu = ops.BetaUpdater(ctx, b["theta"].clone(), b["beta"].clone(), b["pi"], b["dset"], (44, 45), beta_wg)
     g = bu.calculate_grads(dev, m).cpu().numpy()
-    exact = orc.beta_grads(po, theta_h, beta_h, pi_h.reshape(-1), oset, mb, 128, 1, order=1)
+    exact = orc.beta_grads(po, theta_h, beta_h, pi_h.reshape(-1), oset, mb, beta_wg, 1, order=1)
     err = np.abs(g.astype(np.float64) - exact).max() / np.abs(exact).max()
     assert err <= 1e-5, err
     # linearity over edge shards (the multi-GPU contract) at full size
