@@ -239,7 +239,7 @@ class Learner:
             ops.wait_work(w)
         for b0 in range(0, tail, Cc):  # owners hand out their parked tail rows
             b1 = min(b0 + Cc, tail)
-            dist.broadcast(self.tail_buf[b0:b1], src=(b0 // Cc) % R, group=self.group)
+            ops.wait_work(ops.broadcast_async(dist, self.tail_buf[b0:b1], (b0 // Cc) % R, self.group))
         if tail > 0:
             pv[G:G + tail].copy_(self.tail_buf[:tail])
 

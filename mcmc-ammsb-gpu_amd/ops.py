@@ -436,22 +436,50 @@ def pinned(shape, dtype):
     return torch.empty(shape, dtype=dtype, pin_memory=True)
 
 
+def _via_host(dist, group):
+    """gloo has no all_gather_into_tensor and no device transport: when the process group is gloo (several
+    ranks sharing one GPU in tests, or a box without RCCL) the payload is staged through host memory.  Only
+    the exchange changes; every kernel still runs on the device."""
+    return dist.get_backend(group) == "gloo"
+
+
 def all_gather_rows_async(dist, region, chunk, rank, world, group):
     """In-place all-gather of the `world` equal row chunks of `region` (rank r owns chunk r), issued
     asynchronously: RCCL runs it on its own stream behind the work already queued on the current one,
     so the next phi launch overlaps it.  The in-place form (send buffer = own slot of the receive
     buffer) moves each chunk once."""
+    if _via_host(dist, group):
+        mine = region[rank * chunk:(rank + 1) * chunk].cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        for r in range(world):
+            if r != rank:
+                region[r * chunk:(r + 1) * chunk].copy_(parts[r])
+        return None
     return dist.all_gather_into_tensor(region, region[rank * chunk:(rank + 1) * chunk], group=group, async_op=True)
 
 
 def broadcast_async(dist, rows, src, group):
+    if _via_host(dist, group):
+        host = rows.cpu()
+        dist.broadcast(host, src=src, group=group)
+        if dist.get_rank(group) != src:
+            rows.copy_(host)
+        return None
     return dist.broadcast(rows, src=src, group=group, async_op=True)
 
 
 def wait_work(work):
-    work.wait()  # makes the current stream wait for the collective; does not block the host
+    if work is not None:
+        work.wait()  # makes the current stream wait for the collective; does not block the host
 
 
 def all_gather_flat(dist, out, local, rank, world, group):
     """out[r] = rank r's `local` (tiny payloads: [2K] gradient partials, 4 perplexity scalars)."""
+    if _via_host(dist, group):
+        mine = local.reshape(-1).cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        out.copy_(torch.stack(parts).reshape(out.shape))
+        return
     dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), group=group)

@@ -1,0 +1,101 @@
+"""N > 1 on the device: two ranks share the one GPU of the test box (gloo carries the exchange through host
+memory, see ops._via_host), so what runs here is the real sharded path -- the HIP kernels launched over group /
+edge ranges, chunked phi_vec exchange with tail rows, rank-ordered gradient sum, perplexity slices -- against a
+single-process run of the same learner.  RCCL itself needs two GPUs and is exercised by bench.py --gpus N."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, outdir, case, chunks, device_sampling):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib, learner, ops
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    N, K, m, n, iters = case
+    edges = hostlib.generate_graph(N, 8, 12, seed=5)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
+    cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=64, beta_wg_size=64,
+                                           ppx_wg_size=64, strategy="Node", phi_chunks=chunks,
+                                           device_sampling=device_sampling)
+    lrn = learner.Learner(cfg, ds, rank=rank, world_size=world, group=None)
+    p0 = lrn.HeldoutPerplexity()
+    lrn.Run(1)
+    pi1 = lrn.pi.host()
+    lrn.Run(iters - 1)
+    p1 = lrn.HeldoutPerplexity()
+    lrn.drain()
+    np.savez(os.path.join(outdir, "w%d_r%d.npz" % (world, rank)), pi1=pi1, pi=lrn.pi.host(),
+             theta=ops.to_numpy(lrn.theta), beta=ops.to_numpy(lrn.beta), ppx=np.array([p0, p1]),
+             edges=np.array([lrn.edges_done]), seeds=lrn.phiUpdater.rand.host().view(np.uint64))
+    lrn.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,chunks,device_sampling", [
+    ((3000, 256, 256, 8, 6), 4, False),       # K = 256: LDS-streamed phi / beta kernels; first block only -> broadcasts
+    ((150000, 64, 70000, 2, 3), 3, False),    # > 65535 mini-batch nodes: tail rows, 3 overlapped chunks
+    ((150000, 64, 16384, 4, 4), 2, True),     # device-side mini-batch sampler replicated on both ranks
+], ids=["small", "tail-3chunks", "device-sampling"])
+def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    out = str(tmp_path)
+    ctx = mp.get_context("spawn")
+    single = ctx.Process(target=_run, args=(0, 1, 0, out, case, chunks, device_sampling))
+    single.start()
+    single.join(600)
+    assert single.exitcode == 0
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, device_sampling)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    r0 = np.load(os.path.join(out, "w2_r0.npz"))
+    r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    for k in ("pi", "theta", "beta", "ppx", "edges"):       # replicas stay identical
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(r0["pi1"], one["pi1"])             # phi / pi do not depend on the split over ranks
+    assert r0["edges"][0] == one["edges"][0] and r0["ppx"][0] == one["ppx"][0]
+    assert np.allclose(r0["theta"], one["theta"], rtol=2e-5, atol=1e-7)   # gradient summed in another association
+    assert np.allclose(r0["pi"], one["pi"], rtol=5e-4, atol=1e-7)
+    assert abs(r0["ppx"][1] - one["ppx"][1]) <= 1e-5 * one["ppx"][1]
+    L = 64
+    cc = (65535 + 2 * chunks - 1) // (2 * chunks)
+    s0, s1, s = r0["seeds"].reshape(-1, 2), r1["seeds"].reshape(-1, 2), one["seeds"].reshape(-1, 2)
+    lim = min(s.shape[0], s0.shape[0], 65535 * L)
+    owner = (np.arange(lim) // L // cc) % 2
+    assert np.array_equal(s0[:lim][owner == 0], s[:lim][owner == 0])
+    assert np.array_equal(s1[:lim][owner == 1], s[:lim][owner == 1])
