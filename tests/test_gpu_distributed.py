@@ -90,7 +90,10 @@ def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling):
     assert np.array_equal(r0["pi1"], one["pi1"])             # phi / pi do not depend on the split over ranks
     assert r0["edges"][0] == one["edges"][0] and r0["ppx"][0] == one["ppx"][0]
     assert np.allclose(r0["theta"], one["theta"], rtol=2e-5, atol=1e-7)   # gradient summed in another association
-    assert np.allclose(r0["pi"], one["pi"], rtol=5e-4, atol=1e-7)
+    # pi after several iterations: same trajectory up to the rounding of beta (entries are O(1/K); tiny ones sit
+    # next to the 1e-24 clamp and are compared absolutely)
+    d = np.abs(r0["pi"].astype(np.float64) - one["pi"])
+    assert d.max() <= 2e-6 and (d <= 1e-3 * np.abs(one["pi"]) + 1e-7).mean() > 0.999, (d.max(), d.mean())
     assert abs(r0["ppx"][1] - one["ppx"][1]) <= 1e-5 * one["ppx"][1]
     L = 64
     cc = (65535 + 2 * chunks - 1) // (2 * chunks)
