@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libammsb_hip.so")
+LIB_PATH = os.environ.get("AMMSB_HIP_LIB") or os.path.join(_HERE, "libammsb_hip.so")  # override: A/B runs of two builds
 
 RPM_MAX_BLOCKS = 32
 MAX_GROUPS = 65535

@@ -409,6 +409,9 @@ class DeviceMiniBatchSampler:
 # ---- stream / event / collective plumbing used by learner.py (torch is the transport only)
 
 def new_stream(ctx):
+    """Stream of a Sample (sampling + neighbour kernels of the NEXT mini-batch).  Default priority on
+    purpose: a same-box A/B of high priority showed no gain, and at default priority the chain already finishes
+    inside the update_phi launch it overlaps."""
     return torch.cuda.Stream(device=ctx.device)
 
 
