@@ -9,11 +9,18 @@ the reference does not have.
 
 Multi-GPU (one process per GPU, torch.distributed over RCCL): pi, phi_sum, beta/theta and both
 cuckoo sets are replicated; the mini-batch is the same on every rank (same seeds).  Per iteration
-    phi    the 65535 virtual groups are cut into blocks of Cc = ceil(65535 / (R * chunks)); block b
-           belongs to rank b % R and is processed in chunk b // R -- a fixed ownership of RNG streams,
-           so no stream state ever crosses ranks and results do not depend on R.  Chunk c's rows
-           (one block per rank, contiguous) are all-gathered asynchronously while chunk c+1 is being
-           computed; update_pi runs on every rank over all nodes once every chunk has arrived;
+    phi    the first g_rep virtual groups are REPLICATED (every rank computes them: same streams, same
+           results, nothing to send); the other 65535 - g_rep are cut into blocks of
+           Cc = ceil((65535 - g_rep) / (R * chunks)); block b belongs to rank b % R and is processed
+           in chunk b // R -- a fixed ownership of RNG streams, so no stream state ever crosses ranks
+           and results do not depend on R.  Chunk c's rows (one block per rank, contiguous) are
+           all-gathered asynchronously while chunk c+1 and then the replicated groups are being
+           computed; update_pi runs on every rank over all nodes once every chunk has arrived.
+           Why replicate: every rank must end up with all 4K-byte rows, and a row costs about as much
+           to receive over one xGMI link as to recompute (C3, 2 GPUs: 134 MB over a 77 GB/s link =
+           1.75 ms against 0.85 ms to compute the same half), so the fastest split computes part of
+           the "other" rows locally.  g_rep is fixed at start-up: a fraction given in the Config or
+           ("auto") balanced from a timed update_phi and a timed all-gather;
     beta   rank r sums the gradient over its contiguous slice of the mini-batch edges; the R partial
            [2K] vectors are all-gathered and added in rank order; every rank runs the identical
            update_theta (same streams) -> no broadcast;
@@ -57,6 +64,7 @@ class Config:
         self.device_sampling_seed = (1234, 5678)     # (new)
         self.sample_parallel = True                  # MCMC_SAMPLE_PARALLEL, CMakeLists.txt:42
         self.phi_chunks = 4                          # (new) multi-GPU: phi launches per iteration (exchange overlap)
+        self.phi_replicate = "auto"                  # (new) multi-GPU: fraction of groups every rank computes itself
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown Config field %s" % k)
@@ -123,9 +131,10 @@ class Learner:
             raise AmmsbError("held-out set is empty: raise heldout_ratio")
         max_nodes = dataset.max_nodes(cfg.mini_batch_size)
         self.nch = max(1, int(cfg.phi_chunks)) if self.world > 1 else 1
-        blocks = self.world * self.nch
-        self.cc = (MAX_GROUPS + blocks - 1) // blocks  # groups per (rank, chunk) block
-        phi_rows = max(max_nodes, self.cc * blocks if self.world > 1 else 0)
+        self.g_rep = 0
+        self._set_split(0 if cfg.phi_replicate == "auto" else int(round(float(cfg.phi_replicate) * MAX_GROUPS)))
+        # rows for any split: the exchanged blocks may reach past the last group by less than one block each
+        phi_rows = max(max_nodes, MAX_GROUPS + self.world * self.nch if self.world > 1 else 0)
         # learner.cc:105-116
         self.heldoutPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.heldoutEdges,
                                                           self.heldoutSet, cfg.ppx_wg_size)
@@ -158,6 +167,8 @@ class Learner:
         ops.beta_from_theta(c, self.theta, self.beta)
         ops.RandomGammaAndNormalize(c, cfg.eta0, cfg.eta1, self.pi, self.phi)
         ops.synchronize()
+        if self.world > 1 and cfg.phi_replicate == "auto":
+            self._calibrate_split()
 
     # ------------------------------------------------------------------ sampling (learner.cc:175-194)
 
@@ -203,8 +214,55 @@ class Learner:
         import torch.distributed as dist
         return dist
 
+    def _set_split(self, g_rep):
+        """Fix the ownership map: groups [0, g_rep) replicated, the rest in R * chunks blocks of cc groups."""
+        self.g_rep = max(0, min(int(g_rep), MAX_GROUPS))
+        blocks = self.world * self.nch
+        self.cc = max(1, (MAX_GROUPS - self.g_rep + blocks - 1) // blocks)
+
+    def _calibrate_split(self):
+        """Choose g_rep so that computing (replicated + own) groups takes as long as receiving the others'.
+        T = one update_phi over a full synthetic mini-batch (all groups), X = one all-gather of a full
+        phi_vec; a fraction rho replicated costs T (rho + (1 - rho) / R) of compute and X (1 - rho) of
+        exchange.  Stream states and pi are restored / untouched; every rank adopts rank 0's answer."""
+        ops, phi, dist = self.ops, self.phiUpdater, self._dist()
+        if not hasattr(ops, "elapsed_ms"):
+            return  # operator sets without timers (the CPU stand-in of the tests) keep the configured split
+        c, R, K = self.ctx, self.world, self.cfg.K
+        n_nodes = min(self.samples[0].max_nodes, MAX_GROUPS)
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        nodes = c.from_numpy(torch.randperm(self.cfg.N, generator=gen)[:n_nodes].numpy().astype(np.uint32))
+        nbrs = c.from_numpy(torch.randint(0, self.cfg.N, (n_nodes, self.cfg.num_node_sample), generator=gen)
+                            .numpy().astype(np.uint32))
+        keep = phi.rand.seeds.clone()
+        calls = phi.count_calls
+        phi.count_calls = 1
+        per = (n_nodes + R - 1) // R
+        region = phi.phi_vec[:per * R] if phi.phi_vec.shape[0] >= per * R else phi.phi_vec[:(phi.phi_vec.shape[0] // R) * R]
+        chunk = region.shape[0] // R
+
+        def t_phi():
+            phi.update_phi(nodes, nbrs, n_nodes)
+
+        def t_xchg():
+            ops.wait_work(ops.all_gather_rows_async(dist, region, chunk, self.rank, R, self.group))
+        T = min(ops.elapsed_ms(t_phi) for _ in range(3))
+        X = min(ops.elapsed_ms(t_xchg) for _ in range(3)) * (n_nodes / float(chunk * R))
+        phi.rand.seeds.copy_(keep)
+        phi.count_calls = calls
+        # T (rho + (1 - rho) / R) = X (1 - rho)
+        rho = (X - T / R) / (T - T / R + X) if X > T / R else 0.0
+        t = torch.tensor([min(max(rho, 0.0), 0.9)], dtype=torch.float64)
+        t = t.to(c.device)
+        ops.wait_work(ops.broadcast_async(dist, t, 0, self.group))
+        self.calibration = {"phi_ms": T, "xchg_ms": X, "rho": float(t.item())}
+        self._set_split(int(float(t.item()) * MAX_GROUPS))
+        ops.synchronize()
+
     def _phi_sharded(self, s, n_nodes):
-        """update_phi over this rank's blocks, chunk by chunk, with the phi_vec exchange overlapped."""
+        """update_phi over this rank's groups with the phi_vec exchange overlapped: own block of chunk 0,
+        all-gather it (async), own block of chunk 1, ..., then the replicated groups while the last
+        exchanges are still in flight."""
         ops, phi = self.ops, self.phiUpdater
         nodes, nbrs = s.dev_nodes, s.neighbor_sampler.GetData()
         if self.world == 1:
@@ -212,36 +270,43 @@ class Learner:
             return
         dist = self._dist()
         pv = phi.phi_vec
-        R, r, Cc = self.world, self.rank, self.cc
+        R, r, Cc, g0 = self.world, self.rank, self.cc, self.g_rep
         G = min(n_nodes, MAX_GROUPS)
-        tail = n_nodes - G
-        live_chunks = (G + R * Cc - 1) // (R * Cc)  # chunks that contain at least one live group
+        tail = n_nodes - G          # nodes i >= G are the second node of groups 0 .. tail-1; their rows are G + t
+        rep_hi = min(g0, G)         # replicated groups live in this launch: [0, rep_hi)
+        rep_tail = min(tail, rep_hi)
+        # Replicated groups that own tail rows go first: the last all-gather region can reach past row G, and
+        # every sender must already hold the final value of whatever it sends from there.
+        if rep_tail > 0:
+            phi.update_phi(nodes, nbrs, n_nodes, 0, rep_tail)
         works = []
-        for c in range(live_chunks):
-            lo = (c * R + r) * Cc
-            hi = min(lo + Cc, G)
-            if lo < hi:
-                phi.update_phi(nodes, nbrs, n_nodes, lo, hi)
-            base = c * R * Cc
-            last = c == live_chunks - 1
-            if last and tail > 0:
-                # Tail rows i >= G (second node of groups 0 .. tail-1) can lie inside this chunk's
-                # all-gather region; park each owner's tail rows before the region is overwritten.
-                for b0 in range(0, tail, Cc):
-                    if (b0 // Cc) % R == r:
-                        b1 = min(b0 + Cc, tail)
-                        self.tail_buf[b0:b1].copy_(pv[G + b0:G + b1])
-            if G - base <= Cc:  # only rank 0's block is live in this chunk: a broadcast is enough
-                works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
-            else:
-                works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group))
+        if G > g0:
+            live_chunks = (G - g0 + R * Cc - 1) // (R * Cc)  # chunks that contain at least one live exchanged group
+            for c in range(live_chunks):
+                base = g0 + c * R * Cc
+                lo = base + r * Cc
+                hi = min(lo + Cc, G)
+                if lo < hi:
+                    phi.update_phi(nodes, nbrs, n_nodes, lo, hi)
+                if c == live_chunks - 1 and tail > g0:
+                    # exchanged groups with a tail row: park each owner's rows before the region is overwritten
+                    for b0 in range(g0, tail, Cc):
+                        if ((b0 - g0) // Cc) % R == r:
+                            b1 = min(b0 + Cc, tail)
+                            self.tail_buf[b0:b1].copy_(pv[G + b0:G + b1])
+                if G - base <= Cc:  # only rank 0's block is live in this chunk: a broadcast is enough
+                    works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
+                else:
+                    works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group))
+        if rep_hi > rep_tail:
+            phi.update_phi(nodes, nbrs, n_nodes, rep_tail, rep_hi)  # overlaps the exchanges in flight
         for w in works:
             ops.wait_work(w)
-        for b0 in range(0, tail, Cc):  # owners hand out their parked tail rows
-            b1 = min(b0 + Cc, tail)
-            ops.wait_work(ops.broadcast_async(dist, self.tail_buf[b0:b1], (b0 // Cc) % R, self.group))
-        if tail > 0:
-            pv[G:G + tail].copy_(self.tail_buf[:tail])
+        if tail > g0:
+            for b0 in range(g0, tail, Cc):  # owners hand out their parked tail rows
+                b1 = min(b0 + Cc, tail)
+                ops.wait_work(ops.broadcast_async(dist, self.tail_buf[b0:b1], ((b0 - g0) // Cc) % R, self.group))
+            pv[G + g0:G + tail].copy_(self.tail_buf[g0:tail])
 
     def _edge_range(self, n_edges):
         per = (n_edges + self.world - 1) // self.world

@@ -435,6 +435,17 @@ def synchronize():
     torch.cuda.synchronize()
 
 
+def elapsed_ms(fn):
+    """Device time of fn() on the current stream (HIP events), for start-up calibration."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record(torch.cuda.current_stream())
+    fn()
+    b.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    return a.elapsed_time(b)
+
+
 def pinned(shape, dtype):
     return torch.empty(shape, dtype=dtype, pin_memory=True)
 

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, outdir, case, chunks=4):
+def _run(rank, world, port, outdir, case, chunks=4, rep="auto"):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,7 +41,8 @@ def _run(rank, world, port, outdir, case, chunks=4):
     edges = hostlib.generate_graph(N, 8, 12, seed=5)
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
     cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=32, beta_wg_size=32,
-                                           ppx_wg_size=32, strategy="Node", sample_parallel=True, phi_chunks=chunks)
+                                           ppx_wg_size=32, strategy="Node", sample_parallel=True, phi_chunks=chunks,
+                                           phi_replicate=rep)
     lrn = learner.Learner(cfg, ds, ops=oracle_ops, rank=rank, world_size=world, group=group)
     p0 = lrn.HeldoutPerplexity()
     lrn.Run(1)
@@ -51,19 +52,23 @@ def _run(rank, world, port, outdir, case, chunks=4):
     lrn.drain()
     np.savez(os.path.join(outdir, "w%d_r%d.npz" % (world, rank)), pi1=pi1, pi=lrn.pi.host(), phi=lrn.phi.numpy(),
              theta=lrn.theta.numpy(), beta=lrn.beta.numpy(), ppx=np.array([p0, p1]), edges=np.array([lrn.edges_done]),
-             seeds=lrn.phiUpdater.rand.host().view(np.uint64), ppx_state=lrn.heldoutPerplexity.ppx_per_edge.numpy())
+             seeds=lrn.phiUpdater.rand.host().view(np.uint64), ppx_state=lrn.heldoutPerplexity.ppx_per_edge.numpy(),
+             split=np.array([lrn.g_rep, lrn.cc]))
     lrn.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,chunks", [
-    ((3000, 32, 256, 8, 6), 4),        # link + non-link batches; only the first block is live -> broadcasts
-    ((150000, 32, 70000, 2, 2), 1),    # > 65535 mini-batch nodes: both ranks own groups, tail rows beyond group 65534
-    ((150000, 32, 70000, 2, 2), 3),    # same with the exchange cut into 3 overlapped chunks
-], ids=["small", "tail-1chunk", "tail-3chunks"])
-def test_world2_matches_single_process(tmp_path, case, chunks):
+@pytest.mark.parametrize("case,chunks,rep", [
+    ((3000, 32, 256, 8, 6), 4, "auto"),      # link + non-link batches; only the first block is live -> broadcasts
+    ((150000, 32, 70000, 2, 2), 1, 0.0),     # > 65535 mini-batch nodes: both ranks own groups, tail rows beyond group 65534
+    ((150000, 32, 70000, 2, 2), 3, 0.0),     # same with the exchange cut into 3 overlapped chunks
+    ((150000, 32, 70000, 2, 2), 2, 0.3),     # 30 % of the groups replicated (they own the tail rows), the rest exchanged
+    ((3000, 32, 256, 8, 6), 2, 0.002),       # replicated prefix shorter than a link batch: both kinds of group in one step
+    ((150000, 32, 70000, 2, 2), 2, 0.00003), # 1 replicated group, 4465 tail rows: replicated AND exchanged tail rows
+], ids=["small", "tail-1chunk", "tail-3chunks", "replicate-30pct", "replicate-tiny", "mixed-tail"])
+def test_world2_matches_single_process(tmp_path, case, chunks, rep):
     import torch.multiprocessing as mp
     import __graft_entry__ as ge
     ge.build()
@@ -71,7 +76,7 @@ def test_world2_matches_single_process(tmp_path, case, chunks):
     _run(0, 1, 0, out, case)
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, rep)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -94,12 +99,14 @@ def test_world2_matches_single_process(tmp_path, case, chunks):
     # stream ownership is fixed (block b of Cc groups belongs to rank b % 2): each rank advanced exactly
     # its own blocks' streams, and their union equals the single-process state
     L = 32
-    cc = (65535 + 2 * chunks - 1) // (2 * chunks)
+    g_rep, cc = (int(x) for x in r0["split"])
+    assert np.array_equal(r0["split"], r1["split"])
     s0, s1, s = r0["seeds"].reshape(-1, 2), r1["seeds"].reshape(-1, 2), one["seeds"].reshape(-1, 2)
     lim = min(s.shape[0], s0.shape[0], 65535 * L)
-    owner = (np.arange(lim) // L // cc) % 2
-    assert np.array_equal(s0[:lim][owner == 0], s[:lim][owner == 0])
-    assert np.array_equal(s1[:lim][owner == 1], s[:lim][owner == 1])
+    g = np.arange(lim) // L
+    owner = np.where(g < g_rep, -1, ((g - g_rep) // cc) % 2)   # -1: replicated, advanced by both ranks
+    assert np.array_equal(s0[:lim][owner != 1], s[:lim][owner != 1])
+    assert np.array_equal(s1[:lim][owner != 0], s[:lim][owner != 0])
     # perplexity state: each rank owns a contiguous slice of the held-out edges
     H = one["ppx_state"].size
     per = (H + 1) // 2

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, outdir, case, chunks, device_sampling):
+def _run(rank, world, port, outdir, case, chunks, device_sampling, rep):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,7 +40,7 @@ def _run(rank, world, port, outdir, case, chunks, device_sampling):
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
     cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=64, beta_wg_size=64,
                                            ppx_wg_size=64, strategy="Node", phi_chunks=chunks,
-                                           device_sampling=device_sampling)
+                                           device_sampling=device_sampling, phi_replicate=rep)
     lrn = learner.Learner(cfg, ds, rank=rank, world_size=world, group=None)
     p0 = lrn.HeldoutPerplexity()
     lrn.Run(1)
@@ -50,19 +50,21 @@ def _run(rank, world, port, outdir, case, chunks, device_sampling):
     lrn.drain()
     np.savez(os.path.join(outdir, "w%d_r%d.npz" % (world, rank)), pi1=pi1, pi=lrn.pi.host(),
              theta=ops.to_numpy(lrn.theta), beta=ops.to_numpy(lrn.beta), ppx=np.array([p0, p1]),
-             edges=np.array([lrn.edges_done]), seeds=lrn.phiUpdater.rand.host().view(np.uint64))
+             edges=np.array([lrn.edges_done]), seeds=lrn.phiUpdater.rand.host().view(np.uint64),
+             split=np.array([lrn.g_rep, lrn.cc]))
     lrn.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,chunks,device_sampling", [
-    ((3000, 256, 256, 8, 6), 4, False),       # K = 256: LDS-streamed phi / beta kernels; first block only -> broadcasts
-    ((150000, 64, 70000, 2, 3), 3, False),    # > 65535 mini-batch nodes: tail rows, 3 overlapped chunks
-    ((150000, 64, 16384, 4, 4), 2, True),     # device-side mini-batch sampler replicated on both ranks
-], ids=["small", "tail-3chunks", "device-sampling"])
-def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling):
+@pytest.mark.parametrize("case,chunks,device_sampling,rep", [
+    ((3000, 256, 256, 8, 6), 4, False, 0.0),      # K = 256: LDS-streamed phi / beta kernels; first block only -> broadcasts
+    ((150000, 64, 70000, 2, 3), 3, False, 0.0),   # > 65535 mini-batch nodes: tail rows, 3 overlapped chunks
+    ((150000, 64, 16384, 4, 4), 2, True, 0.25),   # device-side mini-batch sampler; a quarter of the groups replicated
+    ((150000, 64, 70000, 2, 3), 2, False, "auto"),  # split calibrated at start-up from a timed launch and exchange
+], ids=["small", "tail-3chunks", "device-sampling", "auto-split"])
+def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling, rep):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device")
@@ -71,12 +73,12 @@ def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling):
     ge.build()
     out = str(tmp_path)
     ctx = mp.get_context("spawn")
-    single = ctx.Process(target=_run, args=(0, 1, 0, out, case, chunks, device_sampling))
+    single = ctx.Process(target=_run, args=(0, 1, 0, out, case, chunks, device_sampling, rep))
     single.start()
     single.join(600)
     assert single.exitcode == 0
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, device_sampling)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, device_sampling, rep)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -96,9 +98,11 @@ def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling):
     assert d.max() <= 2e-6 and (d <= 1e-3 * np.abs(one["pi"]) + 1e-7).mean() > 0.999, (d.max(), d.mean())
     assert abs(r0["ppx"][1] - one["ppx"][1]) <= 1e-5 * one["ppx"][1]
     L = 64
-    cc = (65535 + 2 * chunks - 1) // (2 * chunks)
+    g_rep, cc = (int(x) for x in r0["split"])
+    assert np.array_equal(r0["split"], r1["split"])
     s0, s1, s = r0["seeds"].reshape(-1, 2), r1["seeds"].reshape(-1, 2), one["seeds"].reshape(-1, 2)
     lim = min(s.shape[0], s0.shape[0], 65535 * L)
-    owner = (np.arange(lim) // L // cc) % 2
-    assert np.array_equal(s0[:lim][owner == 0], s[:lim][owner == 0])
-    assert np.array_equal(s1[:lim][owner == 1], s[:lim][owner == 1])
+    g = np.arange(lim) // L
+    owner = np.where(g < g_rep, -1, ((g - g_rep) // cc) % 2)   # -1: replicated, advanced by both ranks
+    assert np.array_equal(s0[:lim][owner != 1], s[:lim][owner != 1])
+    assert np.array_equal(s1[:lim][owner != 0], s[:lim][owner != 0])
