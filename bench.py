@@ -238,7 +238,9 @@ def main():
                        "E": int(ds.E), "heldout_edges": int(ds.heldout_edges.size),
                        "phi_wg": cfg.phi_wg_size, "beta_wg": cfg.beta_wg_size, "ppx_wg": cfg.ppx_wg_size,
                        "sampling": "host(rand_r)" if args.host_sampling else "device",
-                       "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world},
+                       "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
+                       "phi_split": None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
+                                                                 groups_per_block=lrn.cc, chunks=lrn.nch)},
             "ppx_eval_ms": ppx_ms,
             "perplexity": ppx,
             "mini_batch_edges": int(edges_done),
