@@ -66,6 +66,8 @@ struct Config {
 
   // new: draw mini-batches on the device instead of with the host samplers above
   bool device_sampling;
+  ulong2 device_sampling_seed;  // new: streams of the device sampler's candidate draws
+  uint64_t device_sampling_host_seed;  // new: host generator choosing (link?, u) per mini-batch
   // new: rand_r seeds of the two Sample buffers.  The reference takes them from the process-global
   // rand() (sample.cc:132), which is not reproducible once the HIP runtime shares the process (its
   // start-up consumes rand() too); the defaults are what rand() returns first after srand(1).

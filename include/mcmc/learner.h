@@ -8,6 +8,7 @@
 #include <istream>
 #include <memory>
 #include <ostream>
+#include <random>
 
 #include "mcmc/config.h"
 #include "mcmc/data.h"
@@ -34,7 +35,10 @@ class Learner {
   uint64_t MiniBatchEdges() const { return edges_done_; }
 
  private:
-  Float DoSample(Sample* sample);  // learner.cc:175-194
+  Float DoSample(Sample* sample);        // learner.cc:175-194
+  Float DoSampleDevice(Sample* sample);  // Config::device_sampling: csrc/ammsb_minibatch.hip instead of sample.cc
+  bool SerializeDeviceSampler(std::ostream* out);
+  bool ParseDeviceSampler(std::istream* in);
 
   const Config& cfg_;
   clcuda::Queue queue_;
@@ -53,6 +57,16 @@ class Learner {
   SamplerFn sampler_;
   uint32_t stepCount_;
   uint64_t time_, samplingTime_, edges_done_;
+  // device sampler state (only with Config::device_sampling)
+  std::shared_ptr<ammsb_ctx> ctx_;
+  std::unique_ptr<clcuda::Buffer<uint64_t>> csr_offsets_;
+  std::unique_ptr<clcuda::Buffer<Vertex>> csr_targets_;
+  std::vector<uint32_t> degree_;
+  uint32_t candidates_ = 0;
+  std::unique_ptr<random::OpenClRandom> mb_rand_;
+  std::unique_ptr<clcuda::Buffer<uint8_t>> mb_workspace_;
+  std::unique_ptr<clcuda::Buffer<uint32_t>> mb_count_;
+  std::mt19937_64 host_rng_;
   std::unique_ptr<Sample> samples_[2];  // MCMC_SAMPLE_PARALLEL (CMakeLists.txt:42, default ON)
   std::future<Float> futures_[2];
   int phase_;

@@ -151,6 +151,9 @@ struct Sample {  // sample.h:51-92
   clcuda::Buffer<Vertex> dev_nodes;
   unsigned int seed;
   NeighborSampler neighbor_sampler;
+  // sizes of the mini-batch in dev_edges / dev_nodes (== edges.size() / nodes_vec.size() with the host samplers;
+  // the device sampler fills the device buffers only)
+  uint32_t num_edges = 0, num_nodes = 0;
   Sample(const Config& cfg, clcuda::Queue queue);                     // seed = rand(), as sample.cc:132
   Sample(const Config& cfg, clcuda::Queue queue, unsigned int seed);  // reproducible
   bool Serialize(std::ostream* out);  // sample.h:62-91

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <iostream>
 #include <random>
+#include <sstream>
 #include <stdexcept>
 
 using namespace std::chrono;
@@ -46,6 +47,25 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
   if (!sampler_) throw std::runtime_error("Unkown sample strategy");  // learner.cc:146
   samples_[0].reset(new Sample(cfg_, queue_, cfg_.sample_seed[0]));
   samples_[1].reset(new Sample(cfg_, queue_, cfg_.sample_seed[1]));
+  if (cfg_.device_sampling) {
+    if (cfg_.strategy != Node && cfg_.strategy != NodeLink && cfg_.strategy != NodeNonLink)
+      throw std::runtime_error("device sampling implements Node / NodeLink / NodeNonLink only");
+    ctx_ = AcquireContext(cfg_, queue_);
+    std::vector<uint64_t> off;
+    std::vector<Vertex> tgt;
+    cfg_.trainingGraph->ExportCSR(&off, &tgt);
+    if (tgt.empty()) throw std::runtime_error("training graph has no edges");
+    degree_.resize(cfg_.N);
+    for (uint64_t u = 0; u < cfg_.N; ++u) degree_[u] = static_cast<uint32_t>(off[u + 1] - off[u]);
+    csr_offsets_.reset(new clcuda::Buffer<uint64_t>(queue_.GetContext(), queue_, off.begin(), off.end()));
+    csr_targets_.reset(new clcuda::Buffer<Vertex>(queue_.GetContext(), queue_, tgt.begin(), tgt.end()));
+    candidates_ = ammsb_minibatch_candidates(cfg_.N, static_cast<uint32_t>(cfg_.mini_batch_size));
+    if (candidates_ == 0) throw std::runtime_error("device sampling needs N >= 2 * mini_batch");
+    mb_rand_.reset(new random::OpenClRandom(queue_, candidates_, cfg_.device_sampling_seed));
+    mb_workspace_.reset(new clcuda::Buffer<uint8_t>(queue_.GetContext(), ammsb_minibatch_workspace_bytes(candidates_)));
+    mb_count_.reset(new clcuda::Buffer<uint32_t>(queue_.GetContext(), 1));
+    host_rng_.seed(cfg_.device_sampling_host_seed);
+  }
   std::mt19937 mt19937(6342455113);  // learner.cc:150-153
   std::gamma_distribution<Float> gamma_distribution(cfg_.eta0, cfg_.eta1);
   auto gamma = std::bind(gamma_distribution, mt19937);
@@ -58,7 +78,47 @@ Learner::~Learner() {
     if (f.valid()) f.wait();
 }
 
+// Device-side replacement for sampleNode + ExtractNodesFromMiniBatch (sample.cc:249-303, learner.cc:162-173):
+// the coin flip and the choice of u stay on the host, so the sizes are known without a read-back; the m
+// distinct non-links / the edges of u are produced on the device straight into the sample's buffers.
+Float Learner::DoSampleDevice(Sample* sample) {
+  bool link = cfg_.strategy == NodeLink;
+  if (cfg_.strategy == Node) link = (host_rng_() & 1u) != 0;  // rand_r(seed) % 2, sample.cc:297
+  const uint64_t N = cfg_.N;
+  void* stream = sample->queue.stream();
+  if (link) {
+    uint64_t u;
+    do {  // sampleNodeLink retries until the vertex has an edge, sample.cc:254-263
+      u = host_rng_() % N;
+    } while (degree_[u] == 0);
+    const uint32_t n = degree_[u];
+    ThrowIfError(ctx_.get(),
+                 ammsb_minibatch_link(ctx_.get(), csr_offsets_->data(), csr_targets_->data(), static_cast<uint32_t>(u), n,
+                                      sample->dev_edges.data(), sample->dev_nodes.data(), stream),
+                 "ammsb_minibatch_link");
+    sample->queue.Finish();  // the neighbour sampler runs on its own queue
+    sample->num_edges = n;
+    sample->num_nodes = n + 1;
+    sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
+    return static_cast<Float>(N);  // sample.cc:268
+  }
+  const uint32_t m = static_cast<uint32_t>(cfg_.mini_batch_size);
+  const uint64_t u = host_rng_() % N;
+  ThrowIfError(ctx_.get(),
+               ammsb_minibatch_nonlink(ctx_.get(), mb_rand_->Get(), candidates_, static_cast<uint32_t>(u), m,
+                                       &trainingSet_->Get(), heldoutSet_ ? &heldoutSet_->Get() : nullptr,
+                                       mb_workspace_->data(), sample->dev_edges.data(), sample->dev_nodes.data(),
+                                       mb_count_->data(), stream),
+               "ammsb_minibatch_nonlink");
+  sample->queue.Finish();
+  sample->num_edges = m;
+  sample->num_nodes = m + 1;
+  sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
+  return static_cast<Float>(2 * cfg_.E) / static_cast<Float>(m);  // sample.cc:292
+}
+
 Float Learner::DoSample(Sample* sample) {
+  if (cfg_.device_sampling) return DoSampleDevice(sample);
   sample->edges.clear();
   const Float weight = sampler_(cfg_, &sample->edges, &sample->seed);
   ExtractNodesFromMiniBatch(sample->edges, &sample->nodes_vec);
@@ -67,7 +127,9 @@ Float Learner::DoSample(Sample* sample) {
     throw std::runtime_error("mini-batch larger than its device buffers");  // learner.cc:184-189
   sample->dev_edges.Write(sample->queue, sample->edges.size(), sample->edges.data());
   sample->dev_nodes.Write(sample->queue, sample->nodes_vec.size(), sample->nodes_vec.data());
-  sample->neighbor_sampler(static_cast<uint32_t>(sample->nodes_vec.size()), &sample->dev_nodes);
+  sample->num_edges = static_cast<uint32_t>(sample->edges.size());
+  sample->num_nodes = static_cast<uint32_t>(sample->nodes_vec.size());
+  sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
   return weight;
 }
 
@@ -88,9 +150,9 @@ void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
     futures_[1 - phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[1 - phase_].get());
     samplingTime_ += duration_cast<nanoseconds>(high_resolution_clock::now() - ts).count();
     Sample& s = *samples_[phase_];
-    phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), static_cast<uint32_t>(s.nodes_vec.size()));
-    betaUpdater_(&s.dev_edges, static_cast<uint32_t>(s.edges.size()), weight);
-    edges_done_ += s.edges.size();
+    phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), s.num_nodes);
+    betaUpdater_(&s.dev_edges, s.num_edges, weight);
+    edges_done_ += s.num_edges;
     phase_ = 1 - phase_;
   }
   time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
@@ -111,7 +173,31 @@ bool Learner::Serialize(std::ostream* out) {
   return ::mcmc::Serialize(out, &beta_, &queue_) && ::mcmc::Serialize(out, &theta_, &queue_) &&
          ::mcmc::Serialize(out, pi_.get(), &queue_) && ::mcmc::Serialize(out, &phi_, &queue_) &&
          phiUpdater_.Serialize(out) && betaUpdater_.Serialize(out) && heldoutPerplexity_.Serialize(out) &&
-         SerializeMessage(out, props) && samples_[0]->Serialize(out) && samples_[1]->Serialize(out);
+         SerializeMessage(out, props) && samples_[0]->Serialize(out) && samples_[1]->Serialize(out) &&
+         SerializeDeviceSampler(out);
+}
+
+// Trailing extension (the reference's Parse stops after the two samples): the device sampler's host generator,
+// the sizes of the mini-batches sitting in the sample buffers, and its candidate streams.
+bool Learner::SerializeDeviceSampler(std::ostream* out) {
+  if (!cfg_.device_sampling) return true;
+  std::ostringstream st;
+  st << host_rng_ << " " << samples_[0]->num_edges << " " << samples_[0]->num_nodes << " " << samples_[1]->num_edges
+     << " " << samples_[1]->num_nodes << " " << edges_done_;
+  SampleStorage ext;  // reused as a two-bytes-field container: edges = magic, nodes_vec = text state
+  ext.edges = "AMMSB-DEVSAMPLER-CPP-1";
+  ext.nodes_vec = st.str();
+  return SerializeMessage(out, ext) && mb_rand_->Serialize(out);
+}
+
+bool Learner::ParseDeviceSampler(std::istream* in) {
+  if (!cfg_.device_sampling) return true;
+  SampleStorage ext;
+  if (!ParseMessage(in, &ext) || ext.edges != "AMMSB-DEVSAMPLER-CPP-1") return false;
+  std::istringstream st(ext.nodes_vec);
+  st >> host_rng_ >> samples_[0]->num_edges >> samples_[0]->num_nodes >> samples_[1]->num_edges >>
+      samples_[1]->num_nodes >> edges_done_;
+  return !st.fail() && mb_rand_->Parse(in);
 }
 
 bool Learner::Parse(std::istream* in) {
@@ -126,7 +212,7 @@ bool Learner::Parse(std::istream* in) {
   time_ = props.time;
   samplingTime_ = props.samplingTime;
   phase_ = props.phase & 1;
-  if (!(samples_[0]->Parse(in) && samples_[1]->Parse(in))) return false;
+  if (!(samples_[0]->Parse(in) && samples_[1]->Parse(in) && ParseDeviceSampler(in))) return false;
   const Float weight = static_cast<Float>(props.weight);
   futures_[1 - phase_] = std::future<Float>();
   futures_[phase_] = std::async(std::launch::deferred, [weight]() -> Float { return weight; });

@@ -113,6 +113,7 @@ int main(int argc, char** argv) {
       Opt("phi-disable-noise", 0, &cfg.phi_disable_noise, "0 (new)"),
       Opt("sample-seed0", 0, &cfg.sample_seed[0], "1804289383 (new: rand_r seeds of the two sample buffers)"),
       Opt("sample-seed1", 0, &cfg.sample_seed[1], "846930886 (new)"),
+      Opt("device-sampling", 0, &cfg.device_sampling, "0 (new: draw mini-batches on the device)"),
       OptStr("checkpoint-in", 0, &ckptIn),    // (new) Learner::Parse before the first iteration
       OptStr("checkpoint-out", 0, &ckptOut),  // (new) Learner::Serialize after the last one
   };

@@ -180,6 +180,8 @@ bool Sample::Parse(std::istream* in) {
   nodes_vec.resize(storage.nodes_vec.size() / sizeof(Vertex));
   memcpy(nodes_vec.data(), storage.nodes_vec.data(), nodes_vec.size() * sizeof(Vertex));
   seed = storage.seed;
+  num_edges = static_cast<uint32_t>(edges.size());
+  num_nodes = static_cast<uint32_t>(nodes_vec.size());
   return true;
 }
 

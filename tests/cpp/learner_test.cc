@@ -30,8 +30,9 @@ struct RunResult {
   std::vector<mcmc::Float> beta, row;
 };
 
-static RunResult RunOnce(uint64_t N, const std::vector<mcmc::Edge>& edges, uint32_t iters) {
+static RunResult RunOnce(uint64_t N, const std::vector<mcmc::Edge>& edges, uint32_t iters, bool device_sampling = false) {
   mcmc::Config cfg;
+  cfg.device_sampling = device_sampling;
   cfg.N = N;
   cfg.K = 64;
   cfg.mini_batch_size = 256;
@@ -125,6 +126,7 @@ static int CheckpointMode(const std::string& mode, const std::string& dir) {
   const uint32_t iters = 40;
   mcmc::Config cfg;
   FillConfig(&cfg, N);
+  cfg.device_sampling = getenv("AMMSB_TEST_DEVICE_SAMPLING") != nullptr;  // C++-only end-to-end variant
   std::vector<mcmc::Edge> e;
   if (mode == "ckpt") {
     e = mcmc::GenerateSyntheticGraph(N, 16, 16, 7);
@@ -202,6 +204,13 @@ int main(int argc, char** argv) {
   EXPECT(a.p2 < a.p0);                                     // it learns
   EXPECT(a.p0 == b.p0 && a.p1 == b.p1 && a.p2 == b.p2);    // bit-identical reruns
   EXPECT(a.beta == b.beta && a.row == b.row);
+  // device-side mini-batch sampling (Config::device_sampling): learns, reruns are bit-identical
+  const RunResult c = RunOnce(N, edges, 300, true);
+  const RunResult d = RunOnce(N, edges, 300, true);
+  printf("ppx (device sampling): %.6f -> %.6f -> %.6f\n", c.p0, c.p1, c.p2);
+  EXPECT(c.p0 == a.p0);                                    // same initial state
+  EXPECT(std::isfinite(c.p2) && c.p2 < c.p0);
+  EXPECT(c.p1 == d.p1 && c.p2 == d.p2 && c.beta == d.beta && c.row == d.row);
   double s = 0;
   for (float v : a.row) s += v;
   EXPECT(std::fabs(s - 1.0) < 1e-4);
