@@ -235,6 +235,8 @@ void Learner::PrintStats(std::ostream& out) {  // learner.cc:252-299: same categ
   line("GRADS SUM   ", betaUpdater_.GradsSumTime());
   line("UPDATE THETA", betaUpdater_.UpdateThetaTime());
   line("NORM THETA  ", betaUpdater_.NormalizeTime());
+  // not in the reference: the headline rate of this build's benchmark
+  out << "MINI-BATCH EDGES: " << edges_done_ << " (" << (total > 0 ? edges_done_ / total : 0.0) << " edges/s)\n";
 }
 
 void Learner::PrintStats() { PrintStats(std::cerr); }
