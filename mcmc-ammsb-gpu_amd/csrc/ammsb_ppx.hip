@@ -9,6 +9,8 @@
 // single-block kernel in a fixed order.
 #pragma clang fp contract(off)
 
+#include <stdlib.h>
+
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
 
@@ -121,6 +123,149 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void ppx_kernel(const PpxArgs a) {
     a.cnt_partials[2 * gs] = c_link;
     a.cnt_partials[2 * gs + 1] = c_non;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-streamed form for L = 64 and K = 64 * KPT (the shape of update_phi_lds_kernel / beta_grads_lds_kernel):
+// one wave per slot, both pi rows of the next edge arrive by LDS-DMA in a two-edge ring while the
+// current edge is reduced; keys are loaded and probed in the held-out set 64 trips at a time, a window ahead
+// (the probe -- two 64-bit modulos and two dependent 32-byte reads -- used to sit in front of every edge).
+// Same arithmetic and operation order as ppx_kernel<64, KPT>.
+
+typedef __attribute__((address_space(3))) void ppx_lds_void_t;
+typedef const __attribute__((address_space(1))) void ppx_glb_void_t;
+
+template <int KPT, uint32_t D>
+__global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
+  using Grp = Group<64>;
+  constexpr int K = 64 * KPT, HP = KPT / 2, PIECES = KPT / 4;
+  extern __shared__ __align__(16) char smem[];  // [D edges][2 rows][K] floats
+  float* ring = reinterpret_cast<float*>(smem);
+  const int l = threadIdx.x;
+  const uint32_t gs = blockIdx.x;  // the grid is exactly P blocks
+
+  f32x2 bk[HP];
+#pragma unroll
+  for (int p = 0; p < HP; ++p) bk[p] = f32x2{a.beta[2 * (l + 128 * p) + 1], a.beta[2 * (l + 128 * p + 64) + 1]};
+
+  double ll_link = 0.0, ll_non = 0.0;
+  unsigned long long c_link = 0, c_non = 0;
+  const uint32_t n_edges = a.edge_end - a.edge_begin;
+  const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // wave-uniform
+  int phase = 0;
+  const float cm1 = (float)(a.call_count - 1), cc = (float)a.call_count;
+
+  auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
+    const bool ok = tb + l < trips;
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + l) * a.P;
+    const unsigned long long key = a.edges[ok ? e : a.edge_begin];
+    *ymask = __ballot(set_has(a.set, key));  // used as stored: no canonicalisation (perplexity.cc:45-47)
+    return key;
+  };
+  uint32_t tb = 0;
+  unsigned long long ym = 0, ym_next = 0;
+  unsigned long long kv = load_keys(0, &ym), kv_next = load_keys(64, &ym_next);
+  auto key_of = [&](uint32_t t, bool* y) -> unsigned long long {
+    const uint32_t rel = t - tb;  // 0 .. 127 by construction
+    const bool first = rel < 64u;
+    const uint32_t src = first ? rel : rel - 64u;
+    const unsigned long long key = first ? __shfl(kv, (int)src, 64) : __shfl(kv_next, (int)src, 64);
+    *y = (((first ? ym : ym_next) >> src) & 1ull) != 0;
+    return key;
+  };
+  auto request = [&](uint32_t t) {
+    bool y;
+    const unsigned long long key = key_of(t, &y);
+    const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(key >> 32));
+    const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)(key & 0xffffffffu));
+    const float* ra = rpm_row(a.pi, u) + 4 * l;
+    const float* rb = rpm_row(a.pi, v) + 4 * l;
+    char* dst = smem + (t % D) * (2 * K * sizeof(float));
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      __builtin_amdgcn_global_load_lds((ppx_glb_void_t*)(ra + 256 * p), (ppx_lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      __builtin_amdgcn_global_load_lds((ppx_glb_void_t*)(rb + 256 * p),
+                                       (ppx_lds_void_t*)(dst + K * sizeof(float) + 1024 * p), 16, 0, 0);
+  };
+
+  for (uint32_t t = 0; t < D - 1 && t < trips; ++t) request(t);
+  for (uint32_t t = 0; t < trips; ++t) {
+    const float* row_a = ring + (t % D) * 2 * K;
+    const float* row_b = row_a + K;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot (t - 1) % D has been read for the last time
+    if (t + D - 1 < trips) {
+      if (t + D - 1 >= tb + 128) {  // the look-ahead leaves the two key windows: slide them
+        kv = kv_next;
+        ym = ym_next;
+        tb += 64;
+        kv_next = load_keys(tb + 64, &ym_next);
+      }
+      request(t + D - 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 2 * PIECES) : "memory");  // edge t landed, t+1, t+2 in flight
+    } else {
+      const uint32_t ahead = trips - 1 - t;  // 0 .. D-2 edges still in flight behind edge t
+      if (D > 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bool y;
+    (void)key_of(t, &y);
+    y = __builtin_amdgcn_readfirstlane((int)y) != 0;
+
+    float s_part = 0.0f, f_part = 0.0f;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {  // perplexity.cc:100-119
+      const f32x2 pa = f32x2{row_a[l + 128 * p], row_a[l + 128 * p + 64]};
+      const f32x2 pb = f32x2{row_b[l + 128 * p], row_b[l + 128 * p + 64]};
+      const f32x2 f = pa * pb;
+      f_part += f.x;
+      f_part += f.y;
+      const f32x2 w = f * (y ? bk[p] : 1.0f - bk[p]);
+      s_part += w.x;
+      s_part += w.y;
+    }
+    const float fsum = Grp::sum(f_part, (float*)nullptr, phase);
+    float s = Grp::sum(s_part, (float*)nullptr, phase);
+    if (!y) {
+      const float tt = 1.0f - fsum;
+      const float u1 = 1.0f - a.epsilon;
+      s += tt * u1;
+    }
+    if (s < 1.0e-30f) s = 1.0e-30f;
+    if (l == 0) {  // perplexity.cc:139-156
+      const uint64_t pos = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
+      float ppx = a.ppx_per_edge[pos];
+      float m = ppx * cm1;
+      m = m + s;
+      ppx = m / cc;
+      const float ll = logf_cr(ppx);
+      if (y) {
+        c_link += 1;
+        ll_link += (double)ll;
+      } else {
+        c_non += 1;
+        ll_non += (double)ll;
+      }
+      a.ppx_per_edge[pos] = ppx;
+    }
+  }
+  if (l == 0) {
+    a.ll_partials[2 * gs] = ll_link;
+    a.ll_partials[2 * gs + 1] = ll_non;
+    a.cnt_partials[2 * gs] = c_link;
+    a.cnt_partials[2 * gs + 1] = c_non;
+  }
+}
+
+template <int KPT>
+int launch_ppx_lds(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
+  // two-edge ring: 16 KiB per wave, so the 8 slots per CU the launch asks for are resident at once (a three-edge
+  // ring at 24 KiB fits 6 and needs a second round: 0.335 vs 0.250 ms at C3; 1536 slots x 3 edges ties at 0.247)
+  const size_t lds = (size_t)2 * 2 * sizeof(float) * 64 * KPT;
+  ppx_lds_kernel<KPT, 2><<<a.P, 64, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
 }
 
 // fixed-order reduction of the P per-slot partials: thread t adds slots t, t+256, ... ascending,
@@ -242,10 +387,24 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
   if (want < 64) want = 64;
   if (want > ctx->max_ppx_blocks) want = ctx->max_ppx_blocks;
   a.P = span < want ? span : want;
-  AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, {
-                         int rc = launch_ppx<L_, KPT_>(ctx, a, s);
-                         if (rc) return rc;
-                       }));
+  static const bool force_reg = [] {
+    const char* f = getenv("AMMSB_PPX_FORM");
+    return f && f[0] == 'r';
+  }();
+  if (wg == 64 && !force_reg && K == 64u * (uint32_t)kpt && kpt >= 4 && kpt <= 16 && pi->num_cols % 4 == 0) {
+    int rc = AMMSB_OK;
+    switch (kpt) {
+      case 4: rc = launch_ppx_lds<4>(ctx, a, s); break;
+      case 8: rc = launch_ppx_lds<8>(ctx, a, s); break;
+      default: rc = launch_ppx_lds<16>(ctx, a, s); break;
+    }
+    if (rc) return rc;
+  } else {
+    AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, {
+                           int rc = launch_ppx<L_, KPT_>(ctx, a, s);
+                           if (rc) return rc;
+                         }));
+  }
   ppx_reduce_kernel<<<1, 256, 0, s>>>(a.ll_partials, a.cnt_partials, a.P, out);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
