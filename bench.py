@@ -31,6 +31,9 @@ WORKLOADS = {
     "C1": (10_000, 32, 1024, 32, 32, 32),
     "C2": (100_000, 256, 8192, 32, 32, 64),
     "C3": (1_000_000, 1024, 65536, 32, 32, 64),
+    # K = 4096 shapes (not the default; C5 takes minutes of host time to build its 320 M-edge graph and cuckoo sets)
+    "C5s": (2_000_000, 4096, 65536, 32, 32, 64),   # 8.2e9 pi elements: beyond the reference's 32-bit row offsets
+    "C5": (10_000_000, 4096, 65536, 32, 64, 64),
 }
 
 

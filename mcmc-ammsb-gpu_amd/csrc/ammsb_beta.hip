@@ -197,14 +197,19 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
 typedef __attribute__((address_space(3))) void beta_lds_void_t;
 typedef const __attribute__((address_space(1))) void beta_glb_void_t;
 
-template <int KPT>
-__global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
-  using Grp = Group<64>;
-  constexpr int K = 64 * KPT, HP = KPT / 2, PIECES = KPT / 4;
+template <int KPT, int W>
+__global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a) {
+  // L = 64 W lanes per slot: wave wv owns columns 64 wv + ln + L j (the slicing of update_phi_lds_kernel); every
+  // wave streams its own slice of the rows, the two WG_SUMs of an edge share one LDS exchange and one barrier.
+  constexpr int L = 64 * W;
+  constexpr int KW = 64 * KPT;
+  constexpr int K = L * KPT, HP = KPT / 2, PIECES = KPT / 4;
   constexpr uint32_t D = 4;  // ring depth: edge t is reduced while the rows of t+1 .. t+3 are in flight
-  extern __shared__ __align__(16) char smem[];  // [D][K] floats: row of the edge's second end point, then probs
-  float* ring = reinterpret_cast<float*>(smem);
-  const int l = threadIdx.x;
+  extern __shared__ __align__(16) char smem[];  // per wave [D][KW] floats: row slice of the second end point, then probs
+  __shared__ float xsum[W > 1 ? 4 * L : 1];     // two partials per lane, double buffered
+  const int tid = threadIdx.x, wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
+  char* wave_smem = smem + wv * (D * KW * sizeof(float));
+  float* ring = reinterpret_cast<float*>(wave_smem);
   const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks
   const float EPS = a.epsilon;
 
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
     float c[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t k = l + 128 * p + 64 * h;
+      const uint32_t k = tid + 2 * L * p + L * h;
       const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
       const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
       if (gs == 0) a.theta_sum[k] = ts;
@@ -235,14 +240,14 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
 
   // edges of this slot: e(t) = edge_begin + gs + t * P, t < trips
   const uint32_t n_edges = a.edge_end - a.edge_begin;
-  const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // wave-uniform
+  const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // block-uniform
   int phase = 0;
 
-  // keys and link bits: lane i holds trip tb + i (and tb + 64 + i in the second window), probed one
+  // keys and link bits: lane i of every wave holds trip tb + i (and tb + 64 + i in the second window), probed one
   // whole window ahead -- see the register kernel
   auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
-    const bool ok = tb + l < trips;
-    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + l) * a.P;
+    const bool ok = tb + ln < trips;
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + ln) * a.P;
     const unsigned long long edge = a.edges[ok ? e : a.edge_begin];
     const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
     *ymask = __ballot(set_has(a.set, make_edge(u, v)));
@@ -266,11 +271,41 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
     bool y;
     const unsigned long long edge = key_of(t, &y);
     const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)(edge & 0xffffffffu));
-    const float* rb = rpm_row(a.pi, v) + 4 * l;
-    char* dst = smem + (t % D) * (K * sizeof(float));
+    const float* rb = rpm_row(a.pi, v) + (W == 1 ? 4 * tid : L * (ln >> 4) + 64 * wv + 4 * (ln & 15));
+    char* dst = wave_smem + (t % D) * (KW * sizeof(float));
 #pragma unroll
     for (int p = 0; p < PIECES; ++p)
-      __builtin_amdgcn_global_load_lds((beta_glb_void_t*)(rb + 256 * p), (beta_lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((beta_glb_void_t*)(rb + 4 * L * p), (beta_lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+  };
+
+  // WG_SUM over L lanes (sum.cc:20-29) of two values at once
+  auto group_sum2 = [&](float& v0, float& v1) {
+    if constexpr (W == 1) {
+      v0 = Group<64>::wave_tree64(v0);
+      v1 = Group<64>::wave_tree64(v1);
+    } else {
+      float* x = xsum + phase * 2 * L;
+      phase ^= 1;
+      x[tid] = v0;
+      x[L + tid] = v1;
+      __syncthreads();
+      float p0[W], p1[W];
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        p0[i] = x[64 * i + ln];
+        p1[i] = x[L + 64 * i + ln];
+      }
+#pragma unroll
+      for (int st = W / 2; st >= 1; st >>= 1) {
+#pragma unroll
+        for (int i = 0; i < st; ++i) {
+          p0[i] += p0[i + st];
+          p1[i] += p1[i + st];
+        }
+      }
+      v0 = Group<64>::wave_tree64(p0[0]);
+      v1 = Group<64>::wave_tree64(p1[0]);
+    }
   };
 
   f32x2 pa[HP];
@@ -280,7 +315,7 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
 
   for (uint32_t t = 0; t < D - 1 && t < trips; ++t) request(t);
   for (uint32_t t = 0; t < trips; ++t) {
-    float* row_b = ring + (t % D) * K;
+    float* row_b = ring + (t % D) * KW;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot (t - 1) % D has been read for the last time
     if (t + D - 1 < trips) {
       if (t + D - 1 >= tb + 128) {  // the look-ahead leaves the two key windows: slide them (t >= tb + 64 here)
@@ -304,7 +339,7 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
     if (u != cur_u) {
       const float* ra = rpm_row(a.pi, u);
 #pragma unroll
-      for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[l + 128 * p], ra[l + 128 * p + 64]};
+      for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[tid + 2 * L * p], ra[tid + 2 * L * p + L]};
       cur_u = u;
     }
 
@@ -312,20 +347,20 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
     float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
-      const f32x2 pb = f32x2{row_b[l + 128 * p], row_b[l + 128 * p + 64]};
+      const f32x2 pb = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
       const f32x2 f = pa[p] * pb;
       scratch += f.x;
       scratch += f.y;
       const f32x2 pr = (y ? bk[p] : 1.0f - bk[p]) * f;
-      row_b[l + 128 * p] = pr.x;
-      row_b[l + 128 * p + 64] = pr.y;
+      row_b[ln + 128 * p] = pr.x;
+      row_b[ln + 128 * p + 64] = pr.y;
       ppart += pr.x;
       ppart += pr.y;
       const float m0 = fabsf(pr.x), m1 = fabsf(pr.y);
       lo = fminf(fminf(lo, m0 == 0.0f ? 1.0f : m0), m1 == 0.0f ? 1.0f : m1);  // an exact zero divides exactly
     }
-    const float pi_sum = Grp::sum(scratch, (float*)nullptr, phase);  // beta.cc:209-213
-    float probs_sum = Grp::sum(ppart, (float*)nullptr, phase);       // beta.cc:214-217
+    float pi_sum = scratch, probs_sum = ppart;
+    group_sum2(pi_sum, probs_sum);  // beta.cc:209-217
     const float w = y ? EPS : (1.0f - EPS);
     const float prob_0 = w * (1.0f - pi_sum);
     probs_sum += prob_0;
@@ -336,7 +371,7 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
       const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
-        const f32x2 pr = f32x2{row_b[l + 128 * p], row_b[l + 128 * p + 64]};
+        const f32x2 pr = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
         const f32x2 f = div_exact3(pr, psum2, rps2);
         acc0[p] += f * (y ? noo[p] : d0n[p]);
         acc1[p] += f * (y ? d1l[p] : noo[p]);
@@ -344,7 +379,7 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
     } else {
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
-        const f32x2 f = f32x2{row_b[l + 128 * p] / probs_sum, row_b[l + 128 * p + 64] / probs_sum};
+        const f32x2 f = f32x2{row_b[ln + 128 * p] / probs_sum, row_b[ln + 128 * p + 64] / probs_sum};
         acc0[p] += f * (y ? noo[p] : d0n[p]);
         acc1[p] += f * (y ? d1l[p] : noo[p]);
       }
@@ -354,15 +389,15 @@ __global__ __launch_bounds__(64) void beta_grads_lds_kernel(const BetaArgs a) {
   float* out = a.partials + (uint64_t)gs * 2 * K;
 #pragma unroll
   for (int p = 0; p < HP; ++p) {
-    *reinterpret_cast<float2*>(out + 2 * (l + 128 * p)) = make_float2(acc0[p].x, acc1[p].x);
-    *reinterpret_cast<float2*>(out + 2 * (l + 128 * p + 64)) = make_float2(acc0[p].y, acc1[p].y);
+    *reinterpret_cast<float2*>(out + 2 * (tid + 2 * L * p)) = make_float2(acc0[p].x, acc1[p].x);
+    *reinterpret_cast<float2*>(out + 2 * (tid + 2 * L * p + L)) = make_float2(acc0[p].y, acc1[p].y);
   }
 }
 
-template <int KPT>
+template <int KPT, int W>
 int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
-  const size_t lds = 4 * sizeof(float) * 64 * KPT;
-  beta_grads_lds_kernel<KPT><<<a.P, 64, lds, s>>>(a);
+  const size_t lds = (size_t)W * 4 * sizeof(float) * 64 * KPT;
+  beta_grads_lds_kernel<KPT, W><<<a.P, 64 * W, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -556,18 +591,24 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
     const char* f = getenv("AMMSB_BETA_FORM");
     return f && f[0] == 'r';
   }();
-  if (wg == 64 && !force_reg && K == 64u * (uint32_t)kpt && kpt >= 4 && pi->num_cols % 4 == 0) {
-    int rc = AMMSB_OK;
-    switch (kpt) {
-      case 4: rc = launch_grads_lds<4>(ctx, a, s); break;
-      case 8: rc = launch_grads_lds<8>(ctx, a, s); break;
-      default: rc = launch_grads_lds<16>(ctx, a, s); break;
-    }
-    if (rc) return rc;
-  } else {
+  // LDS-streamed kernels: K == wg * kpt exactly; one wave per slot for wg 64, wg / 64 waves with 16 columns per
+  // lane for longer rows (K = 4096: wg 256)
+  bool launched = false;
+  int rc = AMMSB_OK;
+  if (!force_reg && K == wg * (uint32_t)kpt && pi->num_cols % 4 == 0) {
+    launched = true;
+    if (wg == 64 && kpt == 4) rc = launch_grads_lds<4, 1>(ctx, a, s);
+    else if (wg == 64 && kpt == 8) rc = launch_grads_lds<8, 1>(ctx, a, s);
+    else if (wg == 64 && kpt == 16) rc = launch_grads_lds<16, 1>(ctx, a, s);
+    else if (wg == 128 && kpt == 16) rc = launch_grads_lds<16, 2>(ctx, a, s);
+    else if (wg == 256 && kpt == 16) rc = launch_grads_lds<16, 4>(ctx, a, s);
+    else launched = false;
+  }
+  if (rc) return rc;
+  if (!launched) {
     AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT16(kpt, {
-                           int rc = launch_grads<L_, KPT_>(ctx, a, s);
-                           if (rc) return rc;
+                           int rc2 = launch_grads<L_, KPT_>(ctx, a, s);
+                           if (rc2) return rc2;
                          }));
   }
   if ((2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0)

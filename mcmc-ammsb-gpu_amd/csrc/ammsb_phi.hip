@@ -245,52 +245,80 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-template <int KPT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
-  using Grp = Group<64>;
-  constexpr int K = 64 * KPT;
-  constexpr int PIECES = KPT / 4;  // 1 KiB LDS-DMA pieces per row
-  extern __shared__ __align__(16) char smem[];  // [2][K] ring, [K] normals, [n] u32 (neighbour id | link bit)
+template <int KPT, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
+  // L = 64 W lanes per node: wave wv owns columns 64 wv + ln + L j, i.e. KPT chunks of 64 consecutive floats per
+  // row.  Each wave runs the single-wave pipeline on its own slice (own ring, own waits); the only cross-wave
+  // step is the WG_SUM of a neighbour's probs: one LDS exchange and one barrier per row.
+  constexpr int L = 64 * W;
+  constexpr int KW = 64 * KPT;     // floats of a row that one wave handles
+  constexpr int K = L * KPT;
+  constexpr int PIECES = KPT / 4;  // 1 KiB LDS-DMA pieces per wave and row (4 chunks of 256 B each)
+  extern __shared__ __align__(16) char smem[];  // per wave: [2][KW] ring, [KW] normals; then [n] u32 (id | link bit)
   __shared__ ZigTables zig;
-  float* ring = reinterpret_cast<float*>(smem);
-  float* s_noise = ring + 2 * K;
-  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + 3 * K * sizeof(float));
+  __shared__ float xsum[W > 1 ? 2 * L : 1];  // double-buffered lane partials of the cross-wave sum
+  const int tid = threadIdx.x, wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
+  char* wave_smem = smem + wv * (3 * KW * sizeof(float));
+  float* ring = reinterpret_cast<float*>(wave_smem);
+  float* s_noise = ring + 2 * KW;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + W * 3 * KW * sizeof(float));
 
-  const int l = threadIdx.x;
   const uint32_t g = a.group_begin + blockIdx.x;
   if (g >= a.group_end) return;  // block-uniform
   const uint32_t n = a.n;
   const float EPS = a.epsilon;
   if (a.noise_on) zig_load(&zig);
 
-  constexpr int HP = KPT / 2;  // column pairs per lane: pair p = columns l + 64 (2p), l + 64 (2p + 1)
+  constexpr int HP = KPT / 2;  // column pairs per lane: pair p = columns tid + L (2p), tid + L (2p + 1)
   f32x2 bf[HP];
   bool beta_safe = true;
 #pragma unroll
   for (int p = 0; p < HP; ++p) {
-    const float b0 = a.beta[2 * (l + 128 * p) + 1];
-    const float b1 = a.beta[2 * (l + 128 * p + 64) + 1];
+    const float b0 = a.beta[2 * (tid + 2 * L * p) + 1];
+    const float b1 = a.beta[2 * (tid + 2 * L * p + L) + 1];
     bf[p] = f32x2{b0 - EPS, b1 - EPS};
     beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
   }
   ammsb_seed rs = {0, 0};
-  if (a.noise_on) rs = a.seeds[(uint64_t)g * 64 + l];
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * L + tid];
 
-  // request neighbour row q into ring slot `slot`
+  // request this wave's slice of neighbour row q into ring slot `slot`: piece t carries chunks j = 4t .. 4t+3
+  // (16 lanes x 16 B each), so the slice lands as [j][64] and lane ln reads column tid + L j at [j * 64 + ln]
   auto request = [&](uint32_t q, uint32_t slot) {
-    const uint32_t w = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
-    const float* src = rpm_row(a.pi, w) + 4 * l;
-    char* dst = smem + slot * (K * sizeof(float));
+    const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
+    const float* src = rpm_row(a.pi, nbr) + (W == 1 ? 4 * tid : L * (ln >> 4) + 64 * wv + 4 * (ln & 15));
+    char* dst = wave_smem + slot * (KW * sizeof(float));
 #pragma unroll
-    for (int p = 0; p < PIECES; ++p)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 256 * p), (lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+    for (int t = 0; t < PIECES; ++t)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 0);
   };
 
+  // WG_SUM over L lanes (sum.cc:20-29): levels L/2 .. 64 fold wave i + s onto wave i, then the in-wave tree
   int phase = 0;
+  auto group_sum = [&](float v) -> float {
+    if constexpr (W == 1) {
+      return Group<64>::wave_tree64(v);
+    } else {
+      float* x = xsum + phase * L;
+      phase ^= 1;
+      x[tid] = v;
+      __syncthreads();
+      float part[W];
+#pragma unroll
+      for (int i = 0; i < W; ++i) part[i] = x[64 * i + ln];
+#pragma unroll
+      for (int st = W / 2; st >= 1; st >>= 1) {
+#pragma unroll
+        for (int i = 0; i < st; ++i) part[i] += part[i + st];
+      }
+      return Group<64>::wave_tree64(part[0]);
+    }
+  };
+
   for (uint64_t i = g; i < a.n_nodes; i += a.G) {
     const uint32_t node = a.nodes[i];
-    __syncthreads();  // single-wave block: orders the LDS traffic of consecutive nodes
-    for (uint32_t q = l; q < n; q += 64) {
+    __syncthreads();  // orders the LDS traffic of consecutive nodes
+    for (uint32_t q = tid; q < n; q += L) {
       const uint32_t nb = a.neighbors[i * n + q];
       const bool y = set_has(a.set, make_edge(node, nb));
       s_nb[q] = nb | (y ? 0x80000000u : 0u);
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
     f32x2 pi_a[HP], grads[HP], rden[HP];
     bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
 #pragma unroll
-    for (int p = 0; p < HP; ++p) pi_a[p] = f32x2{row_a[l + 128 * p], row_a[l + 128 * p + 64]};
+    for (int p = 0; p < HP; ++p) pi_a[p] = f32x2{row_a[tid + 2 * L * p], row_a[tid + 2 * L * p + L]};
     request(0, 0);  // the first row's flight overlaps the per-node set-up below
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
@@ -314,20 +342,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
       // sqrt(eps_t * phi_k) of the SGLD step does not depend on the gradient: computed here, under the first
       // row's latency, and parked in the noise slot, where the loop multiplies the normal in
       const f32x2 ep = den * a.eps_t;
-      s_noise[l + 128 * p] = sqrtf(ep.x);
-      s_noise[l + 128 * p + 64] = sqrtf(ep.y);
+      s_noise[ln + 128 * p] = sqrtf(ep.x);
+      s_noise[ln + 128 * p + 64] = sqrtf(ep.y);
     }
 
     for (uint32_t q = 0; q < n; ++q) {
       const uint32_t slot = q & 1;
-      float* row = ring + slot * K;
+      float* row = ring + slot * KW;
       // every LDS read of the other slot (row q-1) has been consumed; refill it with row q+1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (q + 1 < n) {
         request(q + 1, slot ^ 1);
-        // one of the node's K normals per iteration, drawn while row q is still on its way (stream order is
+        // one of the lane's KPT normals per iteration, drawn while row q is still on its way (stream order is
         // the ascending column order of the SGLD step below)
-        if (a.noise_on && q < (uint32_t)KPT) s_noise[l + 64 * q] = s_noise[l + 64 * q] * rng_normal(rs, &zig);
+        if (a.noise_on && q < (uint32_t)KPT) s_noise[ln + 64 * q] = s_noise[ln + 64 * q] * rng_normal(rs, &zig);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // row q landed, row q+1 in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -343,12 +371,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
       auto pass1 = [&](auto link) {
 #pragma unroll
         for (int p = 0; p < HP; ++p) {
-          const f32x2 pin = f32x2{row[l + 128 * p], row[l + 128 * p + 64]};
+          const f32x2 pin = f32x2{row[ln + 128 * p], row[ln + 128 * p + 64]};
           const f32x2 tt0 = pin * bf[p];
           const f32x2 tt = decltype(link)::value ? tt0 + e : e - tt0;
           const f32x2 pr = pi_a[p] * tt;
-          row[l + 128 * p] = pr.x;
-          row[l + 128 * p + 64] = pr.y;
+          row[ln + 128 * p] = pr.x;
+          row[ln + 128 * p + 64] = pr.y;
           partial += pr.x;
           partial += pr.y;
           lo = fminf(fminf(lo, fabsf(pr.x)), fabsf(pr.y));
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
       };
       if (y) pass1(std::true_type{});
       else pass1(std::false_type{});
-      const float probs_sum = Grp::sum(partial, (float*)nullptr, phase);  // phi.cc:254-257
+      const float probs_sum = group_sum(partial);  // phi.cc:254-257
 
       // pass 2 (phi.cc:259-263): grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
       if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
         const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
 #pragma unroll
         for (int p = 0; p < HP; ++p) {
-          const f32x2 pr = f32x2{row[l + 128 * p], row[l + 128 * p + 64]};
+          const f32x2 pr = f32x2{row[ln + 128 * p], row[ln + 128 * p + 64]};
           f32x2 qv = div_exact3(pr, psum2, rps2);
           qv = div_exact3(qv, pi_a[p] * ps, rden[p]);
           grads[p] += qv - inv_phi_sum;
@@ -375,8 +403,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
 #pragma unroll
         for (int p = 0; p < HP; ++p) {
           const f32x2 den = pi_a[p] * phi_sum;
-          float q0 = row[l + 128 * p] / probs_sum;
-          float q1 = row[l + 128 * p + 64] / probs_sum;
+          float q0 = row[ln + 128 * p] / probs_sum;
+          float q1 = row[ln + 128 * p + 64] / probs_sum;
           q0 = q0 / den.x;
           q1 = q1 / den.y;
           grads[p] += f32x2{q0 - inv_phi_sum, q1 - inv_phi_sum};
@@ -388,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
     if (a.noise_on) {
 #pragma unroll 1
       for (uint32_t j = n > 0 ? n - 1 : 0; j < (uint32_t)KPT; ++j)
-        s_noise[l + 64 * j] = s_noise[l + 64 * j] * rng_normal(rs, &zig);
+        s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
     const float half = a.eps_t / 2;
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
-      const f32x2 bb = f32x2{s_noise[l + 128 * p], s_noise[l + 128 * p + 64]};  // sqrt(eps_t * phi_k) * noise
+      const f32x2 bb = f32x2{s_noise[ln + 128 * p], s_noise[ln + 128 * p + 64]};  // sqrt(eps_t * phi_k) * noise
       const f32x2 phi_k = pi_a[p] * phi_sum;
       const f32x2 ng = grads[p] * a.Nn;
       f32x2 in = a.alpha - phi_k;
@@ -406,17 +434,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 
       const f32x2 aa = phi_k + drift;
       const f32x2 s2 = aa + bb;
       const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
-      out[l + 128 * p] = v0 > 1e-24f ? v0 : 1e-24f;
-      out[l + 128 * p + 64] = v1 > 1e-24f ? v1 : 1e-24f;
+      out[tid + 2 * L * p] = v0 > 1e-24f ? v0 : 1e-24f;
+      out[tid + 2 * L * p + L] = v1 > 1e-24f ? v1 : 1e-24f;
     }
   }
-  if (a.noise_on) a.seeds[(uint64_t)g * 64 + l] = rs;
+  if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
 }
 
-template <int KPT>
+template <int KPT, int W>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
-  const size_t lds = 3 * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
-  update_phi_lds_kernel<KPT><<<n_groups, 64, lds, s>>>(a);
+  const size_t lds = (size_t)W * 3 * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  update_phi_lds_kernel<KPT, W><<<n_groups, 64 * W, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -559,12 +587,22 @@ extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_r
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
   }();
-  if (wg == 64 && !force_reg && p.K == 64ull * kpt && kpt >= 4 && pi->num_cols % 4 == 0) {
-    switch (kpt) {
-      case 4: return launch_phi_lds<4>(ctx, a, n_groups, s);
-      case 8: return launch_phi_lds<8>(ctx, a, n_groups, s);
-      case 16: return launch_phi_lds<16>(ctx, a, n_groups, s);
-      case 32: return launch_phi_lds<32>(ctx, a, n_groups, s);
+  // LDS-streamed kernels: K == wg * kpt exactly.  One wave per node up to K = 2048 (wg 64); for longer rows the
+  // node is spread over wg / 64 waves with 16 columns per lane (K = 4096: wg 256, K = 8192: wg 512, ...).
+  if (!force_reg && p.K == (uint64_t)wg * kpt && pi->num_cols % 4 == 0 && a.n * sizeof(uint32_t) <= 8192) {
+    if (wg == 64) {
+      switch (kpt) {
+        case 4: return launch_phi_lds<4, 1>(ctx, a, n_groups, s);
+        case 8: return launch_phi_lds<8, 1>(ctx, a, n_groups, s);
+        case 16: return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
+        case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);
+      }
+    } else if (kpt == 16) {
+      switch (wg) {
+        case 128: return launch_phi_lds<16, 2>(ctx, a, n_groups, s);
+        case 256: return launch_phi_lds<16, 4>(ctx, a, n_groups, s);
+        case 512: return launch_phi_lds<16, 8>(ctx, a, n_groups, s);
+      }
     }
   }
   AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, return (launch_phi<L_, KPT_>(ctx, a, n_groups, s))));

@@ -273,7 +273,10 @@ PHI_CASES = [
     (1024, 1000, 5, 64, 64),    # K not a multiple of L, odd n
     (1024, 1024, 32, 64, 64),   # the C3 row shape
     (1024, 1024, 32, 64, 256),
-    (512, 4096, 4, 16, 256),    # the C5 row shape
+    (512, 4096, 4, 16, 256),    # the C5 row shape: LDS-streamed kernel, 4 waves per node
+    (512, 2048, 8, 40, 128),    # 2 waves per node
+    (300, 8192, 3, 6, 512),     # 8 waves per node
+    (3000, 4096, 33, 70, 256),  # more neighbours than one key batch row, odd n
     (4096, 512, 4, 4096, 32),   # wg-phi-test.cc:116-142 shape (N=4096, K=512, n=4, all nodes)
 ]
 
@@ -393,7 +396,8 @@ def test_update_phi_partitioned_pi(orc, hip):
 # --------------------------------------------------------------------------- beta / theta
 
 BETA_CASES = [(2048, 64, 500, 64), (2048, 64, 500, 32), (2048, 256, 3000, 128), (1024, 1000, 300, 256),
-              (4096, 1024, 1024, 64), (4096, 1024, 1024, 256), (4096, 1024, 1024, 1024)]  # wg-beta-test.cc shape
+              (4096, 1024, 1024, 64), (4096, 1024, 1024, 256), (4096, 1024, 1024, 1024),  # wg-beta-test.cc shape
+              (1024, 4096, 1300, 256), (1024, 2048, 300, 128)]  # LDS-streamed kernel with 4 / 2 waves per slot
 
 
 @pytest.mark.parametrize("N,K,n_edges,L", BETA_CASES)
