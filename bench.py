@@ -141,8 +141,14 @@ def main():
 
     N, K, m, n, deg, k_true = WORKLOADS[args.workload]
     t_setup = time.perf_counter()
+
+    def note(msg):  # progress on stderr: the large workloads spend minutes of host time before the first launch
+        if rank == 0:
+            print("[bench %6.1fs] %s" % (time.perf_counter() - t_setup, msg), file=sys.stderr, flush=True)
     edges = hostlib.generate_graph(N, k_true, deg, seed=20260101)
+    note("graph: %d edges" % edges.size)
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.01, rand_seed=1)
+    note("training / held-out sets built")
     cfg = Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, strategy="Node",
                                    phi_wg_size=pick_wg(K, args.phi_wg, 16),   # K=1024 -> 64: the LDS-streamed kernel
                                    beta_wg_size=pick_wg(K, args.beta_wg, 16),  # K=1024 -> 64: the LDS-streamed kernel
@@ -150,6 +156,7 @@ def main():
                                    device_sampling=not args.host_sampling)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
+    note("learner ready")
 
     def sync():
         lrn.drain()
