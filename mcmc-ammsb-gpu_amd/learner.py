@@ -65,6 +65,7 @@ class Config:
         self.sample_parallel = True                  # MCMC_SAMPLE_PARALLEL, CMakeLists.txt:42
         self.phi_chunks = 4                          # (new) multi-GPU: phi launches per iteration (exchange overlap)
         self.phi_replicate = "auto"                  # (new) multi-GPU: fraction of groups every rank computes itself
+        self.force_exchange = False                  # (new, tests) take the multi-rank code path even with one rank
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown Config field %s" % k)
@@ -110,6 +111,7 @@ class Learner:
         self.ops = ops
         self.cfg, self.dataset = cfg, dataset
         self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.sharded = self.world > 1 or bool(getattr(cfg, "force_exchange", False))
         cfg.N, cfg.E = dataset.N, dataset.E
         if cfg.alpha == 0:
             cfg.alpha = float(np.float32(1.0) / np.float32(cfg.K))  # main.cc:153
@@ -130,11 +132,11 @@ class Learner:
         if self.heldoutSet is None:
             raise AmmsbError("held-out set is empty: raise heldout_ratio")
         max_nodes = dataset.max_nodes(cfg.mini_batch_size)
-        self.nch = max(1, int(cfg.phi_chunks)) if self.world > 1 else 1
+        self.nch = max(1, int(cfg.phi_chunks)) if self.sharded else 1
         self.g_rep = 0
         self._set_split(0 if cfg.phi_replicate == "auto" else int(round(float(cfg.phi_replicate) * MAX_GROUPS)))
         # rows for any split: the exchanged blocks may reach past the last group by less than one block each
-        phi_rows = max(max_nodes, MAX_GROUPS + self.world * self.nch if self.world > 1 else 0)
+        phi_rows = max(max_nodes, MAX_GROUPS + self.world * self.nch if self.sharded else 0)
         # learner.cc:105-116
         self.heldoutPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.heldoutEdges,
                                                           self.heldoutSet, cfg.ppx_wg_size)
@@ -157,7 +159,7 @@ class Learner:
             off, tgt = dataset.training_csr()
             self.dev_sampler = ops.DeviceMiniBatchSampler(c, off, tgt, self.trainingSet, self.heldoutSet,
                                                           cfg.mini_batch_size, cfg.device_sampling_seed)
-        if self.world > 1:
+        if self.sharded:
             self.all_grads = c.zeros((self.world, 2 * K), torch.float32)
             self.all_sums = c.zeros((self.world, 4), torch.int64)
             self.tail_buf = c.zeros((max(max_nodes - MAX_GROUPS, 1), K), torch.float32)
@@ -167,7 +169,7 @@ class Learner:
         ops.beta_from_theta(c, self.theta, self.beta)
         ops.RandomGammaAndNormalize(c, cfg.eta0, cfg.eta1, self.pi, self.phi)
         ops.synchronize()
-        if self.world > 1 and cfg.phi_replicate == "auto":
+        if self.sharded and cfg.phi_replicate == "auto":
             self._calibrate_split()
 
     # ------------------------------------------------------------------ sampling (learner.cc:175-194)
@@ -265,7 +267,7 @@ class Learner:
         exchanges are still in flight."""
         ops, phi = self.ops, self.phiUpdater
         nodes, nbrs = s.dev_nodes, s.neighbor_sampler.GetData()
-        if self.world == 1:
+        if not self.sharded:
             phi.update_phi(nodes, nbrs, n_nodes)
             return
         dist = self._dist()
@@ -313,7 +315,7 @@ class Learner:
         return min(self.rank * per, n_edges), min((self.rank + 1) * per, n_edges)
 
     def _reduce_grads(self, local):
-        if self.world == 1:
+        if not self.sharded:
             return local
         dist = self._dist()
         self.ops.all_gather_flat(dist, self.all_grads, local, self.rank, self.world, self.group)
@@ -376,7 +378,7 @@ class Learner:
         per = (H + self.world - 1) // self.world
         lo, hi = min(self.rank * per, H), min((self.rank + 1) * per, H)
         sums = calc.partial(lo, hi)
-        if self.world > 1:
+        if self.sharded:
             dist = self._dist()
             self.ops.all_gather_flat(dist, self.all_sums, sums, self.rank, self.world, self.group)
             parts = [calc.unpack(self.all_sums[r]) for r in range(self.world)]

@@ -106,3 +106,57 @@ def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling, rep):
     owner = np.where(g < g_rep, -1, ((g - g_rep) // cc) % 2)   # -1: replicated, advanced by both ranks
     assert np.array_equal(s0[:lim][owner != 1], s[:lim][owner != 1])
     assert np.array_equal(s1[:lim][owner != 0], s[:lim][owner != 0])
+
+
+def _run_nccl_single(outdir, rep):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib, learner, ops
+    torch.cuda.set_device(0)
+    N, K, m, n, iters = 150000, 64, 70000, 2, 3
+    edges = hostlib.generate_graph(N, 8, 12, seed=5)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
+
+    def cfg(force):
+        return learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=64, beta_wg_size=64,
+                                                ppx_wg_size=64, strategy="Node", phi_chunks=3, phi_replicate=rep,
+                                                force_exchange=force)
+    ref = learner.Learner(cfg(False), ds)
+    ref.Run(iters)
+    want = (ref.pi.host(), ops.to_numpy(ref.theta), ref.HeldoutPerplexity())
+    ref.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    lrn = learner.Learner(cfg(True), ds, rank=0, world_size=1)
+    lrn.Run(iters)
+    got = (lrn.pi.host(), ops.to_numpy(lrn.theta), lrn.HeldoutPerplexity())
+    lrn.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    ok = np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    open(os.path.join(outdir, "nccl_ok_%s" % rep), "w").write("1" if ok else "0")
+
+
+@pytest.mark.parametrize("rep", [0.0, "auto"])
+def test_rccl_calls_with_one_rank(tmp_path, rep):
+    """The exchange code path on the real backend: a one-rank RCCL group runs the chunked in-place
+    all_gather_into_tensor / broadcast / small all-gathers (and, with "auto", the start-up calibration) exactly as a
+    multi-GPU job issues them; with one rank they move nothing, so the run must equal the plain single-GPU learner
+    bit for bit.  What this cannot show is more than one GPU (the test boxes have one)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_run_nccl_single, args=(str(tmp_path), rep))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    assert open(os.path.join(str(tmp_path), "nccl_ok_%s" % rep)).read() == "1"
