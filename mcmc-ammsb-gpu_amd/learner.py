@@ -22,7 +22,7 @@ cuckoo sets are replicated; the mini-batch is the same on every rank (same seeds
            the "other" rows locally.  g_rep is fixed at start-up: a fraction given in the Config or
            ("auto") balanced from a timed update_phi and a timed all-gather;
     beta   rank r sums the gradient over its contiguous slice of the mini-batch edges; the R partial
-           [2K] vectors are all-gathered and added in rank order; every rank runs the identical
+           [2K] vectors are all-gathered and summed (one kernel, fixed association); every rank runs the identical
            update_theta (same streams) -> no broadcast;
     ppx    contiguous slices of the held-out edges; 4 scalars per rank are all-gathered.
 """
@@ -319,10 +319,8 @@ class Learner:
             return local
         dist = self._dist()
         self.ops.all_gather_flat(dist, self.all_grads, local, self.rank, self.world, self.group)
-        total = self.all_grads[0].clone()
-        for r in range(1, self.world):  # fixed rank order
-            total += self.all_grads[r]
-        return total
+        # one reduction kernel over the R rows: the association is fixed by the shape, identical on every rank
+        return torch.sum(self.all_grads, dim=0)
 
     # ------------------------------------------------------------------ the loop (learner.cc:214-250)
 
