@@ -193,6 +193,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     lrn.Run(args.steps)
+    t_enq = time.perf_counter() - t0  # host side done enqueueing (the device may still be running)
     sync()
     dt = time.perf_counter() - t0
     phi.update_phi = orig
@@ -251,6 +252,7 @@ def main():
                        "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
                        "phi_split": None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
                                                                  groups_per_block=lrn.cc, chunks=lrn.nch)},
+            "host_enqueue_ms_per_step": t_enq * 1e3 / args.steps,
             "ppx_eval_ms": ppx_ms,
             "perplexity": ppx,
             "mini_batch_edges": int(edges_done),
