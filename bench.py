@@ -218,7 +218,10 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "update_phi_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
+        wgp = cfg.phi_wg_size
+        lds_form = K % wgp == 0 and ((wgp == 64 and K // wgp in (4, 8, 16, 32)) or (wgp in (128, 256, 512) and K // wgp == 16))
+        kname = ("update_phi_lds_kernel<%d, %d>" % (K // wgp, wgp // 64)) if lds_form else "update_phi_kernel"  # ammsb_phi.hip dispatch
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": len(big),
                     "bytes_per_launch": int(per_node * nodes_per_launch)}
