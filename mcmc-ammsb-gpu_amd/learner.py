@@ -325,6 +325,10 @@ class Learner:
     # ------------------------------------------------------------------ the loop (learner.cc:214-250)
 
     def Run(self, max_iters, signaled=None):
+        with self.ops.pin_current_stream():
+            self._run(max_iters, signaled)
+
+    def _run(self, max_iters, signaled=None):
         ops, cfg = self.ops, self.cfg
         t1 = time.perf_counter()
         nsamples = len(self.samples)

@@ -16,6 +16,7 @@ stream and returns without synchronising (the reference calls queue.Finish() aft
 caller that wants that behaviour calls torch.cuda.synchronize()).
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -26,8 +27,52 @@ from ._capi import AmmsbError, NOISE_OFF, Params, PpxSums, Rpm, SetDesc, check
 SEED_DT = np.dtype([("x", np.uint64), ("y", np.uint64)])
 
 
+# torch.cuda.current_stream() costs ~3 us and every launch needs the handle (a dozen per iteration, a third of
+# the host time of a step).  The streams this module switches to itself (`stream(s)` below) are tracked per
+# thread, and a caller that owns a loop can pin the ambient stream for its duration (`pin_current_stream`);
+# anything else falls back to asking torch.
+_tls = threading.local()
+
+
 def _stream():
+    stack = getattr(_tls, "stack", None)
+    if stack:
+        return stack[-1]
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class pin_current_stream:
+    """with pin_current_stream(): ...  -- the stream that is current on entry is used for every launch of this
+    thread inside the block (unless `stream(s)` switches), without asking torch again."""
+
+    def __enter__(self):
+        if not hasattr(_tls, "stack"):
+            _tls.stack = []
+        _tls.stack.append(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False
+
+
+class _StreamScope:
+    """torch.cuda.stream(s) plus the handle cache above."""
+
+    def __init__(self, s):
+        self.s = s
+        self.tc = torch.cuda.stream(s)
+
+    def __enter__(self):
+        self.tc.__enter__()
+        if not hasattr(_tls, "stack"):
+            _tls.stack = []
+        _tls.stack.append(C.c_void_p(self.s.cuda_stream))
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return self.tc.__exit__(*exc)
 
 
 def _ptr(t):
@@ -416,7 +461,7 @@ def new_stream(ctx):
 
 
 def stream(s):
-    return torch.cuda.stream(s)
+    return _StreamScope(s)
 
 
 def new_event():
@@ -424,11 +469,11 @@ def new_event():
 
 
 def record_event(ev):
-    ev.record(torch.cuda.current_stream())
+    ev.record()  # on torch's current stream
 
 
 def wait_event(ev):
-    torch.cuda.current_stream().wait_event(ev)
+    ev.wait()  # torch's current stream waits for the event
 
 
 def synchronize():

@@ -239,6 +239,10 @@ def new_stream(ctx):
     return None
 
 
+def pin_current_stream():
+    return _Null()
+
+
 def stream(s):
     return _Null()
 
