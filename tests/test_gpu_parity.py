@@ -236,7 +236,8 @@ def test_pi_init_gamma(orc, hip, N, K, rib):
     assert np.array_equal(phi.cpu().numpy(), want_phi)
 
 
-@pytest.mark.parametrize("N,n,wg,n_nodes", [(12000, 20, 32, 65536), (1000, 32, 64, 100), (5000, 8, 32, 70001)])
+@pytest.mark.parametrize("N,n,wg,n_nodes", [(12000, 20, 32, 65536), (1000, 32, 64, 100), (5000, 8, 32, 70001),
+                                             (5000, 200, 32, 300)])  # n = 200: table too large for LDS -> global-table kernel
 def test_neighbor_sampler(orc, hip, N, n, wg, n_nodes):
     # wg-sample-test.cc:22-72 shape (N=12000, n=20, 64k samples) + bit-exactness vs the oracle
     import torch
