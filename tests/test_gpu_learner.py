@@ -213,3 +213,43 @@ def test_cpp_checkpoint_with_device_sampling(env, tmp_path):
     out = subprocess.run([exe, "ckpt", str(tmp_path)], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, AMMSB_TEST_DEVICE_SAMPLING="1"))
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_c1_learner_matches_oracle_learner(env, orc):
+    """BASELINE configs[0] (N = 10k, K = 32, mini-batch 1024, n = 32): the whole iteration sequence -- host rand_r
+    mini-batches, neighbour sampling, update_phi, update_pi, beta gradient, theta step, perplexity -- run by the same
+    Learner once over the HIP operators and once over the oracle-backed CPU operators (tests/oracle_ops.py)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_ops
+    ops, hostlib, learner = env
+    N, K, m, n = 10000, 32, 1024, 32
+    edges = hostlib.generate_graph(N, 32, 32, seed=20260101)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.01, rand_seed=1)
+
+    def cfg():
+        return learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, strategy="Node",
+                                                phi_wg_size=32, beta_wg_size=32, ppx_wg_size=32)
+    dev = learner.Learner(cfg(), ds)
+    cpu = learner.Learner(cfg(), ds, ops=oracle_ops)
+    assert np.array_equal(dev.pi.host(), cpu.pi.host())                      # pi_0 from the device gamma streams
+    assert np.array_equal(ops.to_numpy(dev.theta), cpu.theta.numpy())
+    p_dev, p_cpu = dev.HeldoutPerplexity(), cpu.HeldoutPerplexity()
+    assert abs(p_dev - p_cpu) <= 1e-5 * p_cpu
+    for it in range(1, 7):
+        dev.Run(1)
+        cpu.Run(1)
+        dev.drain()
+        a, b = dev.pi.host(), cpu.pi.host()
+        if it == 1:
+            assert np.array_equal(a, b)                                       # phi / pi are bit-identical given beta
+            assert np.array_equal(ops.to_numpy(dev.phi), cpu.phi.numpy())
+        else:   # beta differs in the last bits (order-free gradient sum), and so does everything after it
+            assert np.abs(a.astype(np.float64) - b).max() <= 2e-6
+        t_dev, t_cpu = ops.to_numpy(dev.theta).astype(np.float64), cpu.theta.numpy().astype(np.float64)
+        assert np.abs(t_dev - t_cpu).max() <= 1e-5 * np.abs(t_cpu).max(), it
+        assert dev.edges_done == cpu.edges_done                               # identical mini-batches
+    p_dev, p_cpu = dev.HeldoutPerplexity(), cpu.HeldoutPerplexity()
+    assert abs(p_dev - p_cpu) <= 1e-5 * p_cpu
+    dev.close(), cpu.close()
