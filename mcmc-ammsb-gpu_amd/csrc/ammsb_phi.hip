@@ -597,6 +597,8 @@ extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_r
         case 16: return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
         case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);
       }
+    } else if (kpt == 8 && wg == 128) {
+      return launch_phi_lds<8, 2>(ctx, a, n_groups, s);
     } else if (kpt == 16) {
       switch (wg) {
         case 128: return launch_phi_lds<16, 2>(ctx, a, n_groups, s);
