@@ -66,6 +66,10 @@ struct Config {
 
   // new: draw mini-batches on the device instead of with the host samplers above
   bool device_sampling;
+  // new: enqueue-only operators (no Finish() after a launch, no per-launch event timers) and, with
+  // device_sampling, a two-stream loop ordered by events instead of host joins.  Results are identical; the
+  // per-kernel times of PrintStats stay zero.
+  bool async_launch;
   ulong2 device_sampling_seed;  // new: streams of the device sampler's candidate draws
   uint64_t device_sampling_host_seed;  // new: host generator choosing (link?, u) per mini-batch
   // new: rand_r seeds of the two Sample buffers.  The reference takes them from the process-global

@@ -38,6 +38,8 @@ class Learner {
   Float DoSample(Sample* sample);        // learner.cc:175-194
   Float DoSampleDevice(Sample* sample);  // Config::device_sampling: csrc/ammsb_minibatch.hip instead of sample.cc
   bool SerializeDeviceSampler(std::ostream* out);
+  void RunAsync(uint32_t max_iters, sig_atomic_t* signaled);  // Config::async_launch + device_sampling
+  void DrainAsync();
   bool ParseDeviceSampler(std::istream* in);
 
   const Config& cfg_;
@@ -67,6 +69,15 @@ class Learner {
   std::unique_ptr<clcuda::Buffer<uint8_t>> mb_workspace_;
   std::unique_ptr<clcuda::Buffer<uint32_t>> mb_count_;
   std::mt19937_64 host_rng_;
+  // async loop: per sample, `ready` (sampling done, recorded on the sample's stream) and `consumed` (the
+  // iteration that used it is done, recorded on the main stream); weights of the enqueued samples
+  void* ev_ready_[2] = {nullptr, nullptr};
+  void* ev_consumed_[2] = {nullptr, nullptr};
+  bool consumed_valid_[2] = {false, false};
+  void* ev_sampler_ = nullptr;  // the device sampler's shared streams / workspace: one call at a time
+  bool sampler_valid_ = false;
+  bool enqueued_[2] = {false, false};
+  Float weights_[2] = {0, 0};
   std::unique_ptr<Sample> samples_[2];  // MCMC_SAMPLE_PARALLEL (CMakeLists.txt:42, default ON)
   std::future<Float> futures_[2];
   int phase_;

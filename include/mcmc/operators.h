@@ -138,6 +138,7 @@ class NeighborSampler {
   std::shared_ptr<ammsb_ctx> ctx_;
   clcuda::Queue queue_;
   uint32_t n_, capacity_, local_;
+  bool async_;
   uint64_t max_nodes_;
   clcuda::Buffer<Vertex> hash_, data_;
   random::OpenClRandom rand_;
@@ -184,6 +185,7 @@ class PhiUpdater {
   clcuda::Buffer<Float> phi_vec_;
   random::OpenClRandom rand_;
   uint32_t count_calls_, local_, flags_;
+  bool async_;
   uint64_t t_update_phi_, t_update_pi_;
 };
 
@@ -216,6 +218,7 @@ class BetaUpdater {
   uint32_t count_calls_, local_;
   clcuda::Buffer<Float> grads_;
   uint64_t t_grads_ = 0, t_update_theta_ = 0;
+  bool async_ = false;
 };
 
 class PerplexityCalculator {

@@ -5,6 +5,8 @@
 #include "mcmc/learner.h"
 #include "mcmc/serialize.h"
 
+#include <hip/hip_runtime.h>
+
 #include <chrono>
 #include <cmath>
 #include <iostream>
@@ -66,6 +68,19 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
     mb_count_.reset(new clcuda::Buffer<uint32_t>(queue_.GetContext(), 1));
     host_rng_.seed(cfg_.device_sampling_host_seed);
   }
+  if (cfg_.async_launch) {
+    if (!cfg_.device_sampling) throw std::runtime_error("async_launch needs device_sampling (the host samplers block)");
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t a, b;
+      clcuda::Check(hipEventCreateWithFlags(&a, hipEventDisableTiming), "hipEventCreate");
+      clcuda::Check(hipEventCreateWithFlags(&b, hipEventDisableTiming), "hipEventCreate");
+      ev_ready_[i] = a;
+      ev_consumed_[i] = b;
+    }
+    hipEvent_t e;
+    clcuda::Check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    ev_sampler_ = e;
+  }
   std::mt19937 mt19937(6342455113);  // learner.cc:150-153
   std::gamma_distribution<Float> gamma_distribution(cfg_.eta0, cfg_.eta1);
   auto gamma = std::bind(gamma_distribution, mt19937);
@@ -76,6 +91,14 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
 Learner::~Learner() {
   for (auto& f : futures_)
     if (f.valid()) f.wait();
+  if (cfg_.async_launch) {
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) {
+      if (ev_ready_[i]) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_ready_[i]));
+      if (ev_consumed_[i]) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_consumed_[i]));
+    }
+    if (ev_sampler_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_sampler_));
+  }
 }
 
 // Device-side replacement for sampleNode + ExtractNodesFromMiniBatch (sample.cc:249-303, learner.cc:162-173):
@@ -86,6 +109,19 @@ Float Learner::DoSampleDevice(Sample* sample) {
   if (cfg_.strategy == Node) link = (host_rng_() & 1u) != 0;  // rand_r(seed) % 2, sample.cc:297
   const uint64_t N = cfg_.N;
   void* stream = sample->queue.stream();
+  // async: the candidate streams, workspace and counter are shared by the two samples' streams
+  auto sampler_begin = [&] {
+    if (cfg_.async_launch && sampler_valid_)
+      clcuda::Check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_sampler_), 0),
+                    "hipStreamWaitEvent");
+  };
+  auto sampler_end = [&] {
+    if (cfg_.async_launch) {
+      clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_sampler_), static_cast<hipStream_t>(stream)), "hipEventRecord");
+      sampler_valid_ = true;
+    }
+  };
+  sampler_begin();
   if (link) {
     uint64_t u;
     do {  // sampleNodeLink retries until the vertex has an edge, sample.cc:254-263
@@ -96,7 +132,8 @@ Float Learner::DoSampleDevice(Sample* sample) {
                  ammsb_minibatch_link(ctx_.get(), csr_offsets_->data(), csr_targets_->data(), static_cast<uint32_t>(u), n,
                                       sample->dev_edges.data(), sample->dev_nodes.data(), stream),
                  "ammsb_minibatch_link");
-    sample->queue.Finish();  // the neighbour sampler runs on its own queue
+    sampler_end();
+    if (!cfg_.async_launch) sample->queue.Finish();  // the neighbour sampler runs on its own queue
     sample->num_edges = n;
     sample->num_nodes = n + 1;
     sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
@@ -110,7 +147,8 @@ Float Learner::DoSampleDevice(Sample* sample) {
                                        mb_workspace_->data(), sample->dev_edges.data(), sample->dev_nodes.data(),
                                        mb_count_->data(), stream),
                "ammsb_minibatch_nonlink");
-  sample->queue.Finish();
+  sampler_end();
+  if (!cfg_.async_launch) sample->queue.Finish();
   sample->num_edges = m;
   sample->num_nodes = m + 1;
   sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
@@ -140,8 +178,50 @@ Float Learner::HeldoutPerplexity() {
   return std::exp(ppx);
 }
 
+// Enqueue-only loop (Config::async_launch, device sampling): the next mini-batch is produced on the other sample's
+// stream while the main stream runs phi / pi / beta; `ready` and `consumed` events order the two, the host never
+// waits inside the loop.  Same launches in the same per-stream order as the synchronous loop => identical results.
+void Learner::RunAsync(uint32_t max_iters, sig_atomic_t* signaled) {
+  hipStream_t main = static_cast<hipStream_t>(queue_.stream());
+  auto enqueue_sample = [&](int idx) {
+    Sample* s = samples_[idx].get();
+    hipStream_t st = static_cast<hipStream_t>(s->queue.stream());
+    if (consumed_valid_[idx])  // do not overwrite buffers a running iteration still reads
+      clcuda::Check(hipStreamWaitEvent(st, static_cast<hipEvent_t>(ev_consumed_[idx]), 0), "hipStreamWaitEvent");
+    weights_[idx] = DoSampleDevice(s);
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_ready_[idx]), st), "hipEventRecord");
+    enqueued_[idx] = true;
+  };
+  if (!enqueued_[phase_]) enqueue_sample(phase_);
+  for (uint64_t i = 0; i < max_iters && (signaled ? !*signaled : true); ++i, ++stepCount_) {
+    const Float weight = weights_[phase_];
+    enqueue_sample(1 - phase_);
+    Sample& s = *samples_[phase_];
+    clcuda::Check(hipStreamWaitEvent(main, static_cast<hipEvent_t>(ev_ready_[phase_]), 0), "hipStreamWaitEvent");
+    phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), s.num_nodes);
+    betaUpdater_(&s.dev_edges, s.num_edges, weight);
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_consumed_[phase_]), main), "hipEventRecord");
+    consumed_valid_[phase_] = true;
+    enqueued_[phase_] = false;
+    edges_done_ += s.num_edges;
+    phase_ = 1 - phase_;
+  }
+}
+
+void Learner::DrainAsync() {
+  if (!cfg_.async_launch) return;
+  for (auto& smp : samples_) smp->queue.Finish();
+  queue_.Finish();
+}
+
 void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
   const auto t1 = high_resolution_clock::now();
+  if (cfg_.async_launch) {
+    RunAsync(max_iters, signaled);
+    DrainAsync();  // Run() returns with the work done, like the reference's
+    time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
+    return;
+  }
   if (stepCount_ == 1 && !futures_[phase_].valid())
     futures_[phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[phase_].get());
   for (uint64_t i = 0; i < max_iters && (signaled ? !*signaled : true); ++i, ++stepCount_) {
@@ -164,10 +244,22 @@ bool Learner::Serialize(std::ostream* out) {
   props.time = time_;
   props.samplingTime = samplingTime_;
   props.phase = phase_;
-  if (!futures_[phase_].valid())  // the reference's constructor has the first sample in flight already
-    futures_[phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[phase_].get());
-  const Float weight = futures_[phase_].get();  // learner.cc:307-311: take the value, then re-arm the future
-  futures_[phase_] = std::async(std::launch::deferred, [weight]() -> Float { return weight; });
+  Float weight;
+  if (cfg_.async_launch) {
+    if (!enqueued_[phase_]) {
+      weights_[phase_] = DoSampleDevice(samples_[phase_].get());
+      clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_ready_[phase_]),
+                                   static_cast<hipStream_t>(samples_[phase_]->queue.stream())), "hipEventRecord");
+      enqueued_[phase_] = true;
+    }
+    DrainAsync();
+    weight = weights_[phase_];
+  } else {
+    if (!futures_[phase_].valid())  // the reference's constructor has the first sample in flight already
+      futures_[phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[phase_].get());
+    weight = futures_[phase_].get();  // learner.cc:307-311: take the value, then re-arm the future
+    futures_[phase_] = std::async(std::launch::deferred, [weight]() -> Float { return weight; });
+  }
   props.weight = weight;
   queue_.Finish();
   return ::mcmc::Serialize(out, &beta_, &queue_) && ::mcmc::Serialize(out, &theta_, &queue_) &&
@@ -214,6 +306,16 @@ bool Learner::Parse(std::istream* in) {
   phase_ = props.phase & 1;
   if (!(samples_[0]->Parse(in) && samples_[1]->Parse(in) && ParseDeviceSampler(in))) return false;
   const Float weight = static_cast<Float>(props.weight);
+  if (cfg_.async_launch) {
+    DrainAsync();
+    weights_[phase_] = weight;
+    enqueued_[phase_] = true;   // the restored sample buffers hold the pending mini-batch
+    enqueued_[1 - phase_] = false;
+    consumed_valid_[0] = consumed_valid_[1] = false;
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_ready_[phase_]),
+                                 static_cast<hipStream_t>(samples_[phase_]->queue.stream())), "hipEventRecord");
+    return true;
+  }
   futures_[1 - phase_] = std::future<Float>();
   futures_[phase_] = std::async(std::launch::deferred, [weight]() -> Float { return weight; });
   return true;

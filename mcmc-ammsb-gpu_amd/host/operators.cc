@@ -135,6 +135,7 @@ NeighborSampler::NeighborSampler(const Config& cfg, clcuda::Queue queue)
       n_(static_cast<uint32_t>(cfg.num_node_sample)),
       capacity_(2 * n_),
       local_(cfg.neighbor_sampler_wg_size),
+      async_(cfg.async_launch),
       max_nodes_(MaxNodes(cfg)),
       hash_(queue.GetContext(), max_nodes_ * capacity_),
       data_(queue.GetContext(), max_nodes_ * n_),
@@ -146,7 +147,7 @@ void NeighborSampler::operator()(uint32_t num_samples, clcuda::Buffer<Vertex>* n
                ammsb_sample_neighbors(ctx_.get(), rand_.Get(), nodes->data(), num_samples, local_, hash_.data(),
                                       data_.data(), queue_.stream()),
                "ammsb_sample_neighbors");
-  queue_.Finish();  // sample.cc:120
+  if (!async_) queue_.Finish();  // sample.cc:120
 }
 
 bool NeighborSampler::Serialize(std::ostream* out) { return rand_.Serialize(out) && ::mcmc::Serialize(out, &data_, &queue_); }
@@ -157,7 +158,8 @@ Sample::Sample(const Config& cfg, clcuda::Queue q, unsigned int s)
       dev_edges(q.GetContext(), MaxEdges(cfg)),
       dev_nodes(q.GetContext(), MaxNodes(cfg)),
       seed(s),
-      neighbor_sampler(cfg, clcuda::Queue(q.GetContext(), q.GetDevice())) {}
+      // async: one stream per sample carries its mini-batch kernels and its neighbour sampler in order
+      neighbor_sampler(cfg, cfg.async_launch ? queue : clcuda::Queue(q.GetContext(), q.GetDevice())) {}
 
 Sample::Sample(const Config& cfg, clcuda::Queue q) : Sample(cfg, q, static_cast<unsigned int>(rand())) {}
 
@@ -223,6 +225,7 @@ PhiUpdater::PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Fl
       count_calls_(0),
       local_(cfg.phi_wg_size),
       flags_(cfg.phi_disable_noise ? AMMSB_NOISE_OFF : 0u),
+      async_(cfg.async_launch),
       t_update_phi_(0),
       t_update_pi_(0) {}
 
@@ -230,6 +233,18 @@ void PhiUpdater::operator()(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex
   if (n == 0) throw std::runtime_error("mini-batch nodes size = 0!");  // phi.cc:732
   if (n > max_nodes_) throw std::runtime_error("grads too small");     // phi.cc:734-737
   ++count_calls_;
+  if (async_) {
+    ThrowIfError(ctx_.get(),
+                 ammsb_update_phi(ctx_.get(), beta_.data(), &pi_->Get(), phi_.data(), &trainingSet_->Get(), nodes.data(),
+                                  neighbors.data(), n, count_calls_, rand_.Get(), local_, flags_, 0, 0xFFFFFFFFu,
+                                  phi_vec_.data(), queue_.stream()),
+                 "ammsb_update_phi");
+    ThrowIfError(ctx_.get(),
+                 ammsb_update_pi(ctx_.get(), &pi_->Get(), phi_.data(), phi_vec_.data(), nodes.data(), n, local_,
+                                 queue_.stream()),
+                 "ammsb_update_pi");
+    return;
+  }
   {
     EventTimer t(queue_.stream());
     ThrowIfError(ctx_.get(),
@@ -280,10 +295,23 @@ BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::B
       rand_(queue, cfg.K, cfg.beta_seed),  // beta.cc:251-252
       count_calls_(0),
       local_(cfg.beta_wg_size),
-      grads_(queue.GetContext(), 2 * cfg.K) {}
+      grads_(queue.GetContext(), 2 * cfg.K) {
+  async_ = cfg.async_launch;
+}
 
 void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale) {
   ++count_calls_;  // beta.cc:336
+  if (async_) {
+    ThrowIfError(ctx_.get(),
+                 ammsb_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), &trainingSet_->Get(), edges->data(),
+                                  num_edges, 0, num_edges, local_, grads_.data(), queue_.stream()),
+                 "ammsb_beta_grads");
+    ThrowIfError(ctx_.get(),
+                 ammsb_update_theta(ctx_.get(), theta_.data(), beta_.data(), grads_.data(), count_calls_, scale,
+                                    rand_.Get(), 0, queue_.stream()),
+                 "ammsb_update_theta");
+    return;
+  }
   EventTimer tg(queue_.stream());
   ThrowIfError(ctx_.get(),
                ammsb_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), &trainingSet_->Get(), edges->data(),

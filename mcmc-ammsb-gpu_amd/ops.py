@@ -425,6 +425,10 @@ class DeviceMiniBatchSampler:
         self.workspace = ctx.empty((int(ctx.lib.ammsb_minibatch_workspace_bytes(self.C)),), torch.uint8)
         self.count = ctx.zeros((1,), torch.int32)
         self.host_rng = np.random.default_rng(host_seed)
+        # The candidate streams, the workspace and the counter are shared by successive calls, which the learner
+        # issues on two alternating streams: each call waits for the previous one's kernels before it starts.
+        self._done = torch.cuda.Event()
+        self._done_valid = False
 
     def __call__(self, strategy, dev_edges, dev_nodes):
         """Enqueue one mini-batch; returns (n_edges, n_nodes, weight)."""
@@ -432,6 +436,8 @@ class DeviceMiniBatchSampler:
         link = {"Node": None, "NodeLink": True, "NodeNonLink": False}.get(strategy, "bad")
         if link == "bad":
             raise AmmsbError("device sampling implements Node / NodeLink / NodeNonLink only")
+        if self._done_valid:
+            self._done.wait()
         if link is None:
             link = bool(self.host_rng.integers(0, 2))  # rand_r(seed) % 2, sample.cc:297
         if link:
@@ -442,12 +448,16 @@ class DeviceMiniBatchSampler:
             n = int(self.degree[u])
             c.check(c.lib.ammsb_minibatch_link(c.handle, _ptr(self.offsets), _ptr(self.targets), u, n,
                                                _ptr(dev_edges), _ptr(dev_nodes), _stream()))
+            self._done.record()
+            self._done_valid = True
             return n, n + 1, float(np.float32(self.N))
         u = int(self.host_rng.integers(0, self.N))
         hs = C.byref(self.heldout_set.desc) if self.heldout_set is not None else None
         c.check(c.lib.ammsb_minibatch_nonlink(c.handle, _ptr(self.rand.seeds), self.C, u, self.m,
                                               C.byref(self.training_set.desc), hs, _ptr(self.workspace),
                                               _ptr(dev_edges), _ptr(dev_nodes), _ptr(self.count), _stream()))
+        self._done.record()
+        self._done_valid = True
         return self.m, self.m + 1, float(np.float32(2 * self.E) / np.float32(self.m))  # sample.cc:292
 
 

@@ -30,9 +30,11 @@ struct RunResult {
   std::vector<mcmc::Float> beta, row;
 };
 
-static RunResult RunOnce(uint64_t N, const std::vector<mcmc::Edge>& edges, uint32_t iters, bool device_sampling = false) {
+static RunResult RunOnce(uint64_t N, const std::vector<mcmc::Edge>& edges, uint32_t iters, bool device_sampling = false,
+                         bool async = false) {
   mcmc::Config cfg;
   cfg.device_sampling = device_sampling;
+  cfg.async_launch = async;
   cfg.N = N;
   cfg.K = 64;
   cfg.mini_batch_size = 256;
@@ -127,6 +129,7 @@ static int CheckpointMode(const std::string& mode, const std::string& dir) {
   mcmc::Config cfg;
   FillConfig(&cfg, N);
   cfg.device_sampling = getenv("AMMSB_TEST_DEVICE_SAMPLING") != nullptr;  // C++-only end-to-end variant
+  cfg.async_launch = getenv("AMMSB_TEST_ASYNC") != nullptr;
   std::vector<mcmc::Edge> e;
   if (mode == "ckpt") {
     e = mcmc::GenerateSyntheticGraph(N, 16, 16, 7);
@@ -211,6 +214,9 @@ int main(int argc, char** argv) {
   EXPECT(c.p0 == a.p0);                                    // same initial state
   EXPECT(std::isfinite(c.p2) && c.p2 < c.p0);
   EXPECT(c.p1 == d.p1 && c.p2 == d.p2 && c.beta == d.beta && c.row == d.row);
+  // enqueue-only loop (Config::async_launch): same launches in the same order => the same bits
+  const RunResult e = RunOnce(N, edges, 300, true, true);
+  EXPECT(e.p1 == c.p1 && e.p2 == c.p2 && e.beta == c.beta && e.row == c.row);
   double s = 0;
   for (float v : a.row) s += v;
   EXPECT(std::fabs(s - 1.0) < 1e-4);

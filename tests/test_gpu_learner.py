@@ -204,14 +204,15 @@ def test_checkpoint_cpp_python_round_trip(env, tmp_path):
     assert bits("cpp_from_py_ppx.txt") == want
 
 
-def test_cpp_checkpoint_with_device_sampling(env, tmp_path):
+@pytest.mark.parametrize("async_launch", [False, True])
+def test_cpp_checkpoint_with_device_sampling(env, tmp_path, async_launch):
     """serialize-test.cc:90-134 for the C++ Learner with Config::device_sampling: the trailing extension record
     (host generator, batch sizes, candidate streams) makes the resumed run bit-identical."""
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mcmc-ammsb-gpu_amd", "learner_test")
     out = subprocess.run([exe, "ckpt", str(tmp_path)], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, AMMSB_TEST_DEVICE_SAMPLING="1"))
+                         env=dict(os.environ, AMMSB_TEST_DEVICE_SAMPLING="1", **({"AMMSB_TEST_ASYNC": "1"} if async_launch else {})))
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
