@@ -15,4 +15,4 @@ hostlib.dump_dataset('$D/c3.bin.gz', 1000000, 0.01, e)
 print('graph', e.size, 'edges,', round(time.time()-t,1), 's')
 PY
 ./mcmc-ammsb-gpu_amd/ammsb_main --load-data 1 --load-file $D/c3.bin.gz -k 1024 -m 65536 -n 32 -x ${2:-200} -i 100 \
-   --phi-wg 64 --beta-wg 64 --ppx-wg 64 --device-sampling ${3:-1} 2>&1 | grep -v "^I   \|^I [a-z_]*:" | tail -25
+   --phi-wg 64 --beta-wg 64 --ppx-wg 64 --device-sampling ${3:-1} --async ${4:-0} 2>&1 | grep -v "^I   \|^I [a-z_]*:" | tail -25
