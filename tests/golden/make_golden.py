@@ -7,14 +7,14 @@ What they do: (1) freeze the oracle -- tests/test_golden.py requires today's ora
 compiler, to reproduce them bit for bit; (2) give the HIP path a committed, oracle-independent target on the GPU box
 (the -m gpu half of the same test file).
 
-    python tools/make_golden.py          # rewrites tests/golden/iteration_K64.npz
+    python tests/golden/make_golden.py          # rewrites tests/golden/iteration_K64.npz
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as orc  # noqa: E402
 

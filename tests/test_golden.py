@@ -1,5 +1,5 @@
 """tests/golden/iteration_K64.npz -- one small, fully specified iteration of the hot path (made by
-tools/make_golden.py from oracle/, NOT from the reference: see that file's header).
+tests/golden/make_golden.py from oracle/, NOT from the reference: see that file's header).
 
   * CPU: today's oracle build reproduces every vector bit for bit (freezes the oracle across hosts/compilers).
   * GPU: the HIP path, driven through the C ABI from the fixture's INPUTS only, reproduces the integer vectors, the
@@ -18,7 +18,7 @@ PATH = os.path.join(HERE, "golden", "iteration_K64.npz")
 
 
 def _gen():
-    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tools", "make_golden.py"))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
