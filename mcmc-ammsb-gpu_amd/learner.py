@@ -421,6 +421,32 @@ class Learner:
         t = self.theta.reshape(-1, 2)
         return (t[:, 0] + t[:, 1]).contiguous()  # BetaUpdater::GetThetaSum(), beta.cc:20-28
 
+    def _gather_sharded_state(self):
+        """Multi-rank runs advance two pieces of state only at their owner: the phi streams of the exchanged group
+        blocks and the running-mean perplexity of each rank's held-out slice.  Before a checkpoint every owner
+        hands its part to the others (a collective: every rank must call Serialize), after which the state is
+        complete and identical everywhere and any rank's file is the checkpoint."""
+        if self.world <= 1:
+            return
+        ops, dist = self.ops, self._dist()
+        self.drain()
+        R, Cc, g0, L = self.world, self.cc, self.g_rep, self.cfg.phi_wg_size
+        seeds = self.phiUpdater.rand.seeds  # [streams, 2] int64, stream = group * L + lane
+        for b in range(R * self.nch):
+            lo, hi = g0 + b * Cc, min(g0 + (b + 1) * Cc, MAX_GROUPS)
+            if lo >= hi or lo * L >= seeds.shape[0]:
+                break
+            rows = seeds[lo * L:min(hi * L, seeds.shape[0])]
+            ops.wait_work(ops.broadcast_async(dist, rows, b % R, self.group))
+        calc = self.heldoutPerplexity
+        H = calc.num_edges
+        per = (H + R - 1) // R
+        for r in range(R):
+            lo, hi = min(r * per, H), min((r + 1) * per, H)
+            if lo < hi:
+                ops.wait_work(ops.broadcast_async(dist, calc.ppx_per_edge[lo:hi], r, self.group))
+        ops.synchronize()
+
     def Serialize(self, out):
         """Write the learner state to the binary stream `out` in the reference's record order
         (learner.cc:316-329): beta, theta, pi, phi, PhiUpdater, BetaUpdater, held-out perplexity,
@@ -428,6 +454,7 @@ class Learner:
         (ignored by the reference's Parse, which stops after the samples) carries the device sampler.
         Every rank holds the same replicated state; rank 0's file is the checkpoint."""
         from . import checkpoint as ck
+        self._gather_sharded_state()
         two = len(self.samples) == 2
         if two and self.futures[self.phase] is None:
             self._launch_sample(self.phase)  # the reference's constructor has it in flight already

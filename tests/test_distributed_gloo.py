@@ -112,3 +112,70 @@ def test_world2_matches_single_process(tmp_path, case, chunks, rep):
     per = (H + 1) // 2
     assert np.allclose(r0["ppx_state"][:per], one["ppx_state"][:per], rtol=1e-4)
     assert np.allclose(r1["ppx_state"][per:], one["ppx_state"][per:], rtol=1e-4)
+
+
+def _run_ckpt(rank, world, port, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import io
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    import oracle_lib
+    oracle_lib.lib().orc_set_num_threads(2)
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib, learner
+    import oracle_ops
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    N, K, m, n = 150000, 32, 70000, 2
+    edges = hostlib.generate_graph(N, 8, 12, seed=5)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
+
+    def cfg():
+        return learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=32, beta_wg_size=32,
+                                                ppx_wg_size=32, strategy="Node", phi_chunks=2, phi_replicate=0.1)
+    a = learner.Learner(cfg(), ds, ops=oracle_ops, rank=rank, world_size=world)
+    a.Run(2)
+    a.HeldoutPerplexity()
+    buf = io.BytesIO()
+    a.Serialize(buf)                       # collective: owners hand out their streams / perplexity slices first
+    a.Run(2)
+    want = (a.pi.host(), a.theta.numpy().copy(), a.HeldoutPerplexity())
+    a.close()
+    shared = [buf.getvalue() if rank == 0 else None]
+    dist.broadcast_object_list(shared, src=0)   # every rank restores from RANK 0's file
+    b = learner.Learner(cfg(), ds, ops=oracle_ops, rank=rank, world_size=world)
+    b.Parse(io.BytesIO(shared[0]))
+    b.Run(2)
+    got = (b.pi.host(), b.theta.numpy().copy(), b.HeldoutPerplexity())
+    b.close()
+    ok = np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    with open(os.path.join(outdir, "ckpt_r%d.bin" % rank), "wb") as f:
+        f.write(buf.getvalue())
+    open(os.path.join(outdir, "ckpt_ok_r%d" % rank), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_checkpoint_is_complete(tmp_path):
+    """A multi-rank checkpoint must carry the phi streams and perplexity means of EVERY rank's blocks: the two ranks
+    write the same bytes, and a fresh two-rank learner restored from them continues bit-identically."""
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    out = str(tmp_path)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run_ckpt, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert open(os.path.join(out, "ckpt_ok_r%d" % r)).read() == "1"
+    a = open(os.path.join(out, "ckpt_r0.bin"), "rb").read()
+    b = open(os.path.join(out, "ckpt_r1.bin"), "rb").read()
+    assert len(a) == len(b) and sum(x != y for x, y in zip(a, b)) <= 16   # only the wall-clock fields may differ
