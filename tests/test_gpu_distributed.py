@@ -160,3 +160,65 @@ def test_rccl_calls_with_one_rank(tmp_path, rep):
     p.join(600)
     assert p.exitcode == 0
     assert open(os.path.join(str(tmp_path), "nccl_ok_%s" % rep)).read() == "1"
+
+
+def _run_ckpt_gpu(rank, world, port, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import io
+    import torch
+    import torch.distributed as dist
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib, learner, ops
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    N, K, m, n = 150000, 64, 70000, 2
+    edges = hostlib.generate_graph(N, 8, 12, seed=5)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
+
+    def cfg():
+        return learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=64, beta_wg_size=64,
+                                                ppx_wg_size=64, strategy="Node", phi_chunks=2, phi_replicate=0.1,
+                                                device_sampling=True)
+    a = learner.Learner(cfg(), ds, rank=rank, world_size=world)
+    a.Run(2)
+    a.HeldoutPerplexity()
+    buf = io.BytesIO()
+    a.Serialize(buf)
+    a.Run(2)
+    want = (a.pi.host(), ops.to_numpy(a.theta), a.HeldoutPerplexity())
+    a.close()
+    shared = [buf.getvalue() if rank == 0 else None]
+    dist.broadcast_object_list(shared, src=0)
+    b = learner.Learner(cfg(), ds, rank=rank, world_size=world)
+    b.Parse(io.BytesIO(shared[0]))
+    b.Run(2)
+    got = (b.pi.host(), ops.to_numpy(b.theta), b.HeldoutPerplexity())
+    b.close()
+    ok = np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    open(os.path.join(outdir, "ckpt_ok_r%d" % rank), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_checkpoint_on_one_gpu(tmp_path):
+    """Multi-rank checkpoint with the HIP kernels and the device sampler: both ranks restore from rank 0's stream
+    and continue bit-identically to the uninterrupted two-rank run."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run_ckpt_gpu, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert open(os.path.join(str(tmp_path), "ckpt_ok_r%d" % r)).read() == "1"
