@@ -59,6 +59,40 @@ def test_record_framing_and_buffers():
         ck.read_buffer(io.BytesIO(raw[:100]), torch.zeros(1000, dtype=torch.int64))
 
 
+def test_row_partitioned_matrix_round_trip():
+    # serialize-test.cc:41-54 (RowPartitionedMatrix): 11 full blocks + 1 short one, shape checked on the way back
+    class Rpm:
+        def __init__(self, rows, cols, rib):
+            self.rows, self.cols, self.rib = rows, cols, rib
+            self.blocks = [torch.zeros((min(rib, rows - r), cols)) for r in range(0, rows, rib)]
+
+        def Rows(self):
+            return self.rows
+
+        def Cols(self):
+            return self.cols
+
+        def RowsPerBlock(self):
+            return self.rib
+
+        def Blocks(self):
+            return self.blocks
+    a = Rpm(1000, 33, 91)
+    assert len(a.blocks) == 11
+    rng = np.random.default_rng(1)
+    for b in a.blocks:
+        b.copy_(torch.from_numpy(rng.random(tuple(b.shape), dtype=np.float32)))
+    out = io.BytesIO()
+    ck.write_rpm(out, a)
+    b = Rpm(1000, 33, 91)
+    ck.read_rpm(io.BytesIO(out.getvalue()), b)
+    assert all(torch.equal(x, y) for x, y in zip(a.blocks, b.blocks))
+    first = ck.decode(out.getvalue()[8:8 + struct.unpack_from("<Q", out.getvalue(), 0)[0]])
+    assert first == {1: 1000, 2: 33, 3: 91}
+    with pytest.raises(ck.CheckpointError):
+        ck.read_rpm(io.BytesIO(out.getvalue()), Rpm(1000, 33, 100))
+
+
 def test_large_buffer_is_streamed(monkeypatch):
     monkeypatch.setattr(ck, "_PIECE", 1000)
     v = torch.arange(5000, dtype=torch.int32)
