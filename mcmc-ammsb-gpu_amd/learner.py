@@ -59,6 +59,12 @@ class Config:
         self.neighbor_seed = (3337, 54351)
         self.phi_disable_noise = False
         self.strategy = "Node"
+        # kernel-variant knobs of the reference (config.h:60-66): accepted for source compatibility; every value
+        # selects this build's one kernel family
+        self.phi_mode = "PHI_NODE_PER_WORKGROUP_NAIVE"
+        self.phi_probs_shared = self.phi_grads_shared = self.phi_pi_shared = True
+        self.phi_vector_width = 1
+        self.sum_grads_vector_width = 1
         self.sample_seeds = (1804289383, 846930886)  # (new) Sample::seed = rand() twice, sample.cc:132
         self.device_sampling = False                 # (new) draw mini-batches on the device
         self.device_sampling_seed = (1234, 5678)     # (new)

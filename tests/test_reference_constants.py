@@ -67,3 +67,75 @@ def test_scalar_constants():
     h = re.search(r"\(k \^ (\d+)\) % capacity", sample).group(1)
     for path in ("oracle/ammsb_oracle.c", "mcmc-ammsb-gpu_amd/csrc/ammsb_core.hip"):
         assert ("^ %su" % h) in open(os.path.join(ROOT, path)).read(), path
+
+
+def test_cli_flags_and_defaults_equal_main_cc():
+    """Every option main.cc registers (name, short form, default) appears in `ammsb_main --help` with the same
+    short form and an equivalent default."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    main_cc = open("/root/reference/main.cc").read()
+    block = main_cc[main_cc.index("options.add_options()"):main_cc.index("po::variables_map")]
+    block = re.sub(r"#ifdef MCMC_CALC_TRAIN_PPX.*?#endif", "", block, flags=re.S)   # compiled out by default
+    opts = re.findall(r'\("([A-Za-z0-9_-]+)(?:,([a-z]))?",\s*(?:po::value\(&[\w.]+\)(?:->default_value\((.*?)\))?|"[^"]*")\s*(?:,\s*"[^"]*")?\)',
+                      block, re.S)
+    assert len(opts) >= 33, len(opts)
+    exe = os.path.join(ROOT, "mcmc-ammsb-gpu_amd", "ammsb_main")
+    text = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=60).stdout
+
+    def norm(v):
+        v = v.strip().replace("mcmc::", "")
+        v = {"true": "1", "false": "0"}.get(v, v)
+        m = re.fullmatch(r"\{(\d+),\s*(\d+)\}", v)
+        if m:
+            return "%s,%s" % m.groups()
+        try:
+            return repr(float(v))
+        except ValueError:
+            return v
+    for name, short, default in opts:
+        if name == "help":
+            continue
+        pat = (r"-%s \[ --%s \] arg" % (short, re.escape(name))) if short else (r"--%s arg" % re.escape(name))
+        m = re.search(pat + r"(?: \(=([^)]*)\))?", text)
+        assert m, name
+        if default:
+            assert m.group(1) is not None, name
+            assert norm(m.group(1).split(" ")[0]) == norm(default), (name, m.group(1), default)
+
+
+def test_config_defaults_equal_config_h():
+    """`mcmc::Config()` (reference config.h:68-101): every default assignment has the same value in this build's
+    host/config.cc and in the Python Config."""
+    ref = open(os.path.join(REF, "config.h")).read()
+    body = ref[ref.index("Config() {"):]
+    body = re.sub(r"#ifdef MCMC_CALC_TRAIN_PPX.*?#endif", "", body[:body.index("\n  }\n")], flags=re.S)
+    ref_defaults = dict(re.findall(r"^\s*(\w+) = ([^;]+);", body, re.M))
+    assert len(ref_defaults) >= 27
+    mine = open(os.path.join(ROOT, "mcmc-ammsb-gpu_amd", "host", "config.cc")).read()
+    mine = mine[mine.index("Config::Config()"):]
+    mine_defaults = dict(re.findall(r"^\s*(\w+) = ([^;]+);", mine[:mine.index("\n}")], re.M))
+    for k, v in ref_defaults.items():
+        assert k in mine_defaults, k
+        a, b = v.strip(), mine_defaults[k].strip()
+        try:
+            assert float(a.rstrip("f")) == float(b.rstrip("f")), (k, a, b)
+        except ValueError:
+            assert a.replace(" ", "") == b.replace(" ", ""), (k, a, b)
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd.learner import Config
+    py = Config()
+    for k, v in ref_defaults.items():
+        got = getattr(py, k)
+        v = v.strip()
+        m = re.fullmatch(r"\{(\d+),\s*(\d+)\}", v)
+        if m:
+            assert tuple(got) == (int(m.group(1)), int(m.group(2))), k
+        elif v in ("true", "false"):
+            assert got == (v == "true"), k
+        elif re.fullmatch(r"[A-Za-z_]+", v):
+            assert str(got) in (v, {"PHI_NODE_PER_WORKGROUP_NAIVE": "PHI_NODE_PER_WORKGROUP_NAIVE"}.get(v, v)), k
+        else:
+            assert float(got) == float(v), k
