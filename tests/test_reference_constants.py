@@ -139,3 +139,58 @@ def test_config_defaults_equal_config_h():
             assert str(got) in (v, {"PHI_NODE_PER_WORKGROUP_NAIVE": "PHI_NODE_PER_WORKGROUP_NAIVE"}.get(v, v)), k
         else:
             assert float(got) == float(v), k
+
+
+def test_checkpoint_records_follow_protos_proto():
+    """Every record of a checkpoint written by this build decodes to exactly the field numbers and wire types that
+    mcmc/protos.proto declares for the message expected at that position (record order: learner.cc:316-329,
+    sample.h:62-75, phi.cc:765-771, beta.cc:386-397, perplexity.cc:276-283)."""
+    import io
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    proto = open(os.path.join(REF, "protos.proto")).read()
+    wt = {"bytes": 2, "uint32": 0, "uint64": 0, "int32": 0, "double": 1}
+    messages = {}
+    for name, body in re.findall(r"message (\w+) \{(.*?)\}", proto, re.S):
+        fields = re.findall(r"required (\w+) \w+ = (\d+);", body)
+        messages[name] = [(int(num), wt.get(ty, 2)) for ty, num in fields]   # message-typed fields are length-delimited
+    assert {"VectorStorage", "RpmProperties", "BetaProperties", "PhiProperties", "PerplexityProperties", "SampleStorage",
+            "LearnerProperties"} <= set(messages)
+    import ammsb_pkg
+    ammsb_pkg.load()
+    import numpy as np
+    import oracle_ops
+    from mcmc_ammsb_gpu_amd import checkpoint as ck, hostlib
+    from mcmc_ammsb_gpu_amd.learner import Config, Learner
+    rng = np.random.default_rng(3)
+    u, v = rng.integers(0, 1024, 1500, dtype=np.uint64), rng.integers(0, 1024, 1500, dtype=np.uint64)
+    e = np.unique((np.minimum(u, v)[u != v] << np.uint64(32)) | np.maximum(u, v)[u != v])
+    ds = hostlib.Dataset.robust(1024, e, 0.1)
+    lrn = Learner(Config(heldout_ratio=0.1), ds, ops=oracle_ops)
+    lrn.Run(3)
+    out = io.BytesIO()
+    lrn.Serialize(out)
+    lrn.close()
+    sample = ["SampleStorage"] + ["VectorStorage"] * 4
+    order = (["VectorStorage", "VectorStorage", "RpmProperties", "VectorStorage", "VectorStorage",   # beta theta pi phi
+              "VectorStorage", "PhiProperties", "VectorStorage", "VectorStorage", "BetaProperties",  # updaters
+              "PerplexityProperties", "VectorStorage", "LearnerProperties"] + sample + sample)
+    raw, pos = out.getvalue(), 0
+    for expect in order:
+        (size,) = struct.unpack_from("<Q", raw, pos)
+        msg = raw[pos + 8:pos + 8 + size]
+        pos += 8 + size
+        tags, p = [], 0
+        while p < len(msg):   # walk the top-level fields without materialising the payloads
+            key, p = ck._read_varint(msg, p)
+            num, w = key >> 3, key & 7
+            tags.append((num, w))
+            if w == 0:
+                _, p = ck._read_varint(msg, p)
+            elif w == 1:
+                p += 8
+            else:
+                n, p = ck._read_varint(msg, p)
+                p += n
+        assert tags == messages[expect], (expect, tags)
+    assert pos == len(raw)
