@@ -126,6 +126,10 @@ int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, con
 int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
                     const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, void* stream);
 
+/* BetaUpdater::GetThetaSum(), beta.h:27: theta_sum[k] = theta[k,0] + theta[k,1] as the last ammsb_beta_grads of
+ * this context computed it (kernel sum_theta, beta.cc:30-37), copied into out[K] (device) on `stream`. */
+int ammsb_theta_sum(ammsb_ctx* ctx, float* out, void* stream);
+
 /* BetaUpdater::operator() gradient half, beta.cc:334-366: sum_theta + calculate_grads_partial +
  * sum_grads over edges [edge_begin, edge_end) of the mini-batch.  grads_out: [2K] = the sum over
  * those edges (the mathematical sum; the reference's serial partial-row order is not reproduced, and

@@ -197,6 +197,7 @@ class BetaUpdater {
               const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
   void operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale);
   clcuda::Buffer<Float>& GetGrads() { return grads_; }
+  clcuda::Buffer<Float>& GetThetaSum();  // beta.h:27: as of the last operator()
   // device time in ns.  The reference's five stages (beta.h:30-34) are two launches here: theta_sum +
   // partial gradients + their sum are one call, update_theta + theta->beta normalisation the other.
   uint64_t ThetaSumTime() const { return 0; }
@@ -218,6 +219,7 @@ class BetaUpdater {
   uint32_t count_calls_, local_;
   clcuda::Buffer<Float> grads_;
   uint64_t t_grads_ = 0, t_update_theta_ = 0;
+  clcuda::Buffer<Float> theta_sum_;
   bool async_ = false;
 };
 

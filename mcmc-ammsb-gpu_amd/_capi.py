@@ -50,6 +50,7 @@ SIGNATURES = {
     "ammsb_eps_t": [_P(Params), _u32],
     "ammsb_ctx_create": [C.c_int, _P(Params), _P(_vp)],
     "ammsb_ctx_destroy": [_vp],
+    "ammsb_theta_sum": [_vp, _vp, _vp],
     "ammsb_ctx_params": [_vp, _P(Params)],
     "ammsb_rng_init": [_vp, _vp, _u64, _u64, _u64, _vp],
     "ammsb_set_has": [_vp, _P(SetDesc), _vp, _u64, _vp, _vp],

@@ -619,6 +619,13 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
   return AMMSB_OK;
 }
 
+extern "C" int ammsb_theta_sum(ammsb_ctx* ctx, float* out, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && out, "null argument");
+  AMMSB_HIP(ctx, hipMemcpyAsync(out, ctx->theta_sum, sizeof(float) * ctx->params.K, hipMemcpyDeviceToDevice,
+                                as_stream(stream)));
+  return AMMSB_OK;
+}
+
 extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, uint32_t step_count,
                                   float scale, ammsb_seed* seeds, uint32_t flags, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds, "null argument");

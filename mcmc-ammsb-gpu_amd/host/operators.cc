@@ -295,8 +295,15 @@ BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::B
       rand_(queue, cfg.K, cfg.beta_seed),  // beta.cc:251-252
       count_calls_(0),
       local_(cfg.beta_wg_size),
-      grads_(queue.GetContext(), 2 * cfg.K) {
+      grads_(queue.GetContext(), 2 * cfg.K),
+      theta_sum_(queue.GetContext(), cfg.K) {
   async_ = cfg.async_launch;
+}
+
+clcuda::Buffer<Float>& BetaUpdater::GetThetaSum() {
+  ThrowIfError(ctx_.get(), ammsb_theta_sum(ctx_.get(), theta_sum_.data(), queue_.stream()), "ammsb_theta_sum");
+  queue_.Finish();
+  return theta_sum_;
 }
 
 void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale) {

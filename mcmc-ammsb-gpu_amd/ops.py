@@ -356,6 +356,13 @@ class BetaUpdater:
     def GetGrads(self):
         return self.grads
 
+    def GetThetaSum(self):
+        """theta_sum of the last gradient launch (beta.h:27), as a device tensor [K]."""
+        c = self.ctx
+        out = c.empty((c.params.K,), torch.float32)
+        c.check(c.lib.ammsb_theta_sum(c.handle, _ptr(out), _stream()))
+        return out
+
 
 def beta_from_theta(ctx, theta, beta):
     ctx.check(ctx.lib.ammsb_beta_from_theta(ctx.handle, _ptr(theta), _ptr(beta), _stream()))

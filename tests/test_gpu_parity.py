@@ -417,6 +417,9 @@ def test_beta_pipeline(orc, hip, N, K, n_edges, L):
         g = upd.calculate_grads(dev_edges, mbe.size)
         pr.sync()
         got_g = g.cpu().numpy().copy()
+        ts = np.zeros(K, dtype=np.float32)
+        orc.lib().orc_sum_theta(theta_h, ts, K)
+        assert np.array_equal(upd.GetThetaSum().cpu().numpy().view(np.uint32), ts.view(np.uint32))  # beta.h:27
         exact = orc.beta_grads(pr.p_orc, theta_h, beta_h, pr.pi_h.reshape(-1), pr.oset, mbe, L, 1, order=1)
         ref = orc.beta_grads(pr.p_orc, theta_h, beta_h, pr.pi_h.reshape(-1), pr.oset, mbe, L, 1, order=0)
         # the sum over edges is order-free by contract: compare against the float64 accumulation of the
