@@ -123,11 +123,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the MI355X path has no CPU fallback")
+    # AMMSB_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices, the exchange is staged through host memory) -- for checking the code path, never for numbers
+    backend = os.environ.get("AMMSB_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -246,7 +254,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: %s backend, ranks share GPUs)" % backend,
             "config": {"workload": "%s: synthetic a-MMSB graph N=%d avg-degree=%d K=%d mini-batch=%d n=%d strategy=Node"
                                    % (args.workload, N, deg, K, m, n),
                        "E": int(ds.E), "heldout_edges": int(ds.heldout_edges.size),
