@@ -260,7 +260,13 @@ class Learner:
         phi.count_calls = calls
         # T (rho + (1 - rho) / R) = X (1 - rho)
         rho = (X - T / R) / (T - T / R + X) if X > T / R else 0.0
-        t = torch.tensor([min(max(rho, 0.0), 0.9)], dtype=torch.float64)
+        rho = min(max(rho, 0.0), 1.0)
+
+        def cost(r):
+            return max(T * (r + (1.0 - r) / R), X * (1.0 - r))
+        if cost(1.0) <= cost(rho) * 1.02:  # links so slow that exchanging anything loses: every rank computes all groups
+            rho = 1.0
+        t = torch.tensor([rho], dtype=torch.float64)
         t = t.to(c.device)
         ops.wait_work(ops.broadcast_async(dist, t, 0, self.group))
         self.calibration = {"phi_ms": T, "xchg_ms": X, "rho": float(t.item())}
