@@ -142,7 +142,7 @@ class Learner:
         self.g_rep = 0
         self._set_split(0 if cfg.phi_replicate == "auto" else int(round(float(cfg.phi_replicate) * MAX_GROUPS)))
         # rows for any split: the exchanged blocks may reach past the last group by less than one block each
-        phi_rows = max(max_nodes, MAX_GROUPS + self.world * self.nch if self.sharded else 0)
+        phi_rows = max(max_nodes, MAX_GROUPS + self.world * max(1, int(cfg.phi_chunks)) if self.sharded else 0)
         # learner.cc:105-116
         self.heldoutPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.heldoutEdges,
                                                           self.heldoutSet, cfg.ppx_wg_size)
@@ -166,6 +166,10 @@ class Learner:
             self.dev_sampler = ops.DeviceMiniBatchSampler(c, off, tgt, self.trainingSet, self.heldoutSet,
                                                           cfg.mini_batch_size, cfg.device_sampling_seed)
         if self.sharded:
+            # the replicated groups run on their own stream next to the exchanged blocks: with 8 ranks a block is
+            # ~1800 single-wave nodes, well under what the chip holds, and the two launches fill it together
+            self.rep_stream = ops.new_stream(c)
+            self.ev_fork, self.ev_join = ops.new_event(), ops.new_event()
             self.all_grads = c.zeros((self.world, 2 * K), torch.float32)
             self.all_sums = c.zeros((self.world, 4), torch.int64)
             self.tail_buf = c.zeros((max(max_nodes - MAX_GROUPS, 1), K), torch.float32)
@@ -225,6 +229,9 @@ class Learner:
     def _set_split(self, g_rep):
         """Fix the ownership map: groups [0, g_rep) replicated, the rest in R * chunks blocks of cc groups."""
         self.g_rep = max(0, min(int(g_rep), MAX_GROUPS))
+        # keep a rank's block of a chunk near or above one chip-load of single-wave nodes (3 per SIMD = 3072)
+        own = (MAX_GROUPS - self.g_rep) // max(self.world, 1)
+        self.nch = max(1, min(max(1, int(self.cfg.phi_chunks)), own // 3072)) if self.sharded else 1
         blocks = self.world * self.nch
         self.cc = max(1, (MAX_GROUPS - self.g_rep + blocks - 1) // blocks)
 
@@ -293,6 +300,13 @@ class Learner:
         # every sender must already hold the final value of whatever it sends from there.
         if rep_tail > 0:
             phi.update_phi(nodes, nbrs, n_nodes, 0, rep_tail)
+        forked = rep_hi > rep_tail
+        if forked:  # replicated groups: side stream, ordered after everything queued on this one so far
+            ops.record_event(self.ev_fork)
+            with ops.stream(self.rep_stream):
+                ops.wait_event(self.ev_fork)
+                phi.update_phi(nodes, nbrs, n_nodes, rep_tail, rep_hi)
+                ops.record_event(self.ev_join)
         works = []
         if G > g0:
             live_chunks = (G - g0 + R * Cc - 1) // (R * Cc)  # chunks that contain at least one live exchanged group
@@ -312,10 +326,10 @@ class Learner:
                     works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
                 else:
                     works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group))
-        if rep_hi > rep_tail:
-            phi.update_phi(nodes, nbrs, n_nodes, rep_tail, rep_hi)  # overlaps the exchanges in flight
         for w in works:
             ops.wait_work(w)
+        if forked:
+            ops.wait_event(self.ev_join)
         if tail > g0:
             for b0 in range(g0, tail, Cc):  # owners hand out their parked tail rows
                 b1 = min(b0 + Cc, tail)
