@@ -300,7 +300,9 @@ class Learner:
         # every sender must already hold the final value of whatever it sends from there.
         if rep_tail > 0:
             phi.update_phi(nodes, nbrs, n_nodes, 0, rep_tail)
-        forked = rep_hi > rep_tail
+        # side stream only when a block is too small to fill the chip by itself (measured, tools/shard_bench.py:
+        # 8 ranks 0.487 -> 0.448 ms, 2 ranks 1.25 -> 1.32 ms)
+        forked = rep_hi > rep_tail and Cc < 4096
         if forked:  # replicated groups: side stream, ordered after everything queued on this one so far
             ops.record_event(self.ev_fork)
             with ops.stream(self.rep_stream):
@@ -326,6 +328,8 @@ class Learner:
                     works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
                 else:
                     works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group))
+        if rep_hi > rep_tail and not forked:
+            phi.update_phi(nodes, nbrs, n_nodes, rep_tail, rep_hi)  # overlaps the exchanges in flight
         for w in works:
             ops.wait_work(w)
         if forked:
