@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
     char* dst = wave_smem + slot * (KW * sizeof(float));
 #pragma unroll
     for (int t = 0; t < PIECES; ++t)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
   };
 
   // WG_SUM over L lanes (sum.cc:20-29): levels L/2 .. 64 fold wave i + s onto wave i, then the in-wave tree
