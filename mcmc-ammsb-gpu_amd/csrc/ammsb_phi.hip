@@ -285,6 +285,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
   // request this wave's slice of neighbour row q into ring slot `slot`: piece t carries chunks j = 4t .. 4t+3
   // (16 lanes x 16 B each), so the slice lands as [j][64] and lane ln reads column tid + L j at [j * 64 + ln]
   auto request = [&](uint32_t q, uint32_t slot) {
+    // aux 2 = nt (non-temporal): a neighbour row is read once per launch; keeping it out of the caches' way
+    // measured -4 % per launch (same-box A/B, five alternations)
     const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
     const float* src = rpm_row(a.pi, nbr) + (W == 1 ? 4 * tid : L * (ln >> 4) + 64 * wv + 4 * (ln & 15));
     char* dst = wave_smem + slot * (KW * sizeof(float));
