@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
     f32x2 pi_a[HP], grads[HP], rden[HP];
     bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
 #pragma unroll
-    for (int p = 0; p < HP; ++p) pi_a[p] = f32x2{row_a[tid + 2 * L * p], row_a[tid + 2 * L * p + L]};
+    for (int p = 0; p < HP; ++p)
+      pi_a[p] = f32x2{__builtin_nontemporal_load(row_a + tid + 2 * L * p), __builtin_nontemporal_load(row_a + tid + 2 * L * p + L)};
     request(0, 0);  // the first row's flight overlaps the per-node set-up below
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
@@ -436,8 +437,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
       const f32x2 aa = phi_k + drift;
       const f32x2 s2 = aa + bb;
       const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
-      out[tid + 2 * L * p] = v0 > 1e-24f ? v0 : 1e-24f;
-      out[tid + 2 * L * p + L] = v1 > 1e-24f ? v1 : 1e-24f;
+      __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + tid + 2 * L * p);
+      __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
     }
   }
   if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
