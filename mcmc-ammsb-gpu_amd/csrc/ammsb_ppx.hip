@@ -71,7 +71,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void ppx_kernel(const PpxArgs a) {
     for (int j = 0; j < KPT; ++j) {
       const uint32_t k = l + j * L;
       const uint32_t ck = k < K ? k : K - 1;
-      const float xa = ra[ck], xb = rb[ck];
+      const float xa = __builtin_nontemporal_load(ra + ck), xb = __builtin_nontemporal_load(rb + ck);  // read once per pass
       pa[b][j] = k < K ? xa : 0.0f;
       pb[b][j] = xb;
     }
