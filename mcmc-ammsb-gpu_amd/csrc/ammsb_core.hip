@@ -273,36 +273,50 @@ __global__ __launch_bounds__(64) void sample_neighbors_kernel(ammsb_seed* seeds,
 __global__ __launch_bounds__(64) void sample_neighbors_lds_kernel(ammsb_seed* seeds, const uint32_t* nodes,
                                                                    uint32_t n_nodes, uint32_t N, uint32_t n,
                                                                    uint32_t gsize, uint32_t* table, uint32_t* packed) {
-  extern __shared__ uint32_t lds[];  // [capacity][64]
+  // [capacity][65]: slot j of lane l at j * 65 + l.  A lane probing its own table touches one bank whatever the
+  // slot; the transposed read-back below (consecutive lanes = consecutive slots of one node) strides by 65 and
+  // is conflict-free too (a stride of 64 would put all 64 lanes on one bank).
+  extern __shared__ uint32_t lds[];
+  constexpr uint32_t S = 65;
   const uint32_t lane = threadIdx.x;
   const uint32_t gid = blockIdx.x * 64 + lane;
   const uint32_t capacity = 2 * n;
   const bool owner = gid < gsize && gid < n_nodes;
   ammsb_seed seed = owner ? seeds[gid] : ammsb_seed{0, 0};
   const uint32_t max_id = N - 1;
+  const FastMod mod_n = fast_mod_init((uint64_t)max_id + 1);
+  const uint64_t cap_m = ~0ull / capacity + 1;  // Lemire: a % capacity == mulhi64(cap_m * a, capacity) for 32-bit a
+  // (row, col) of element x = lane + 64 k of a row-major [live][width] array, advanced without a division
+  auto advance = [](uint32_t& row, uint32_t& col, uint32_t width) {
+    col += 64;
+    while (col >= width) {
+      col -= width;
+      ++row;
+    }
+  };
   for (uint32_t base = blockIdx.x * 64; base < n_nodes; base += gsize) {  // uniform across the block
     const uint32_t i = base + lane;
     const bool on = owner && i < n_nodes;
     const uint32_t live = min(64u, min(n_nodes - base, gsize - blockIdx.x * 64));  // lanes with a node this round
-    for (uint32_t j = 0; j < capacity; ++j) lds[j * 64 + lane] = N;
+    for (uint32_t j = 0; j < capacity; ++j) lds[j * S + lane] = N;
     if (on) {
       const uint32_t node = nodes[i];
       for (uint32_t j = 0; j < n; ++j) {
         uint32_t r, val;
         do {
           do {
-            r = (uint32_t)(rng_next(seed) % (uint64_t)(max_id + 1));
+            r = (uint32_t)fast_mod(rng_next(seed), mod_n);  // randint(seed, 0, max_id), random.cl.inc:37-39
           } while (r == node);
-          const uint32_t l1 = (r ^ 553105253u) % capacity;
-          const uint32_t l2 = 1u + (capacity << 1);
-          for (uint32_t t = 0;; ++t) {
-            const uint32_t offset = (l1 + t * l2) % capacity;
-            val = lds[offset * 64 + lane];
+          // h1 = (r ^ 553105253) % capacity; the probe step 1 + 2 capacity is 1 modulo capacity (sample.cc:15-21)
+          uint32_t offset = (uint32_t)__umul64hi(cap_m * (uint64_t)(r ^ 553105253u), capacity);
+          for (;;) {
+            val = lds[offset * S + lane];
             if (val == r) break;
             if (val == max_id + 1) {
-              lds[offset * 64 + lane] = r;
+              lds[offset * S + lane] = r;
               break;
             }
+            offset = offset + 1 == capacity ? 0 : offset + 1;
           }
         } while (val == r);
       }
@@ -310,18 +324,38 @@ __global__ __launch_bounds__(64) void sample_neighbors_lds_kernel(ammsb_seed* se
     __syncthreads();
     // table image: `live` consecutive rows of `capacity` words
     uint32_t* tout = table + (uint64_t)base * capacity;
-    for (uint32_t x = lane; x < live * capacity; x += 64) tout[x] = lds[(x % capacity) * 64 + x / capacity];
+    {
+      uint32_t row = 0, col = lane;
+      while (col >= capacity) {
+        col -= capacity;
+        ++row;
+      }
+      for (uint32_t x = lane; x < live * capacity; x += 64) {
+        tout[x] = lds[col * S + row];
+        advance(row, col, capacity);
+      }
+    }
     __syncthreads();
     if (on) {  // compact in place: count <= j, so the write never overtakes the read
       uint32_t count = 0;
       for (uint32_t j = 0; j < capacity && count < n; ++j) {
-        const uint32_t v = lds[j * 64 + lane];
-        if (v != N) lds[(count++) * 64 + lane] = v;
+        const uint32_t v = lds[j * S + lane];
+        if (v != N) lds[(count++) * S + lane] = v;
       }
     }
     __syncthreads();
     uint32_t* pout = packed + (uint64_t)base * n;
-    for (uint32_t x = lane; x < live * n; x += 64) pout[x] = lds[(x % n) * 64 + x / n];
+    {
+      uint32_t row = 0, col = lane;
+      while (col >= n) {
+        col -= n;
+        ++row;
+      }
+      for (uint32_t x = lane; x < live * n; x += 64) {
+        pout[x] = lds[col * S + row];
+        advance(row, col, n);
+      }
+    }
     __syncthreads();
   }
   if (owner) seeds[gid] = seed;
@@ -338,7 +372,7 @@ extern "C" int ammsb_sample_neighbors(ammsb_ctx* ctx, ammsb_seed* seeds, const u
   const uint32_t maxg = AMMSB_MAX_GROUPS / wg;
   if (groups > maxg) groups = maxg;
   const uint32_t gsize = groups * wg;
-  const size_t lds_bytes = (size_t)2 * n * 64 * sizeof(uint32_t);
+  const size_t lds_bytes = (size_t)2 * n * 65 * sizeof(uint32_t);
   if (lds_bytes <= 64 * 1024)
     sample_neighbors_lds_kernel<<<div_up(gsize, 64), 64, lds_bytes, as_stream(stream)>>>(
         seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed);

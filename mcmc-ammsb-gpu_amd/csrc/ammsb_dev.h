@@ -136,6 +136,19 @@ __device__ __forceinline__ float rng_gamma(ammsb_seed& s, const ZigTables* t, fl
   return r * v;
 }
 
+// x % d for a 64-bit draw and a 31-bit modulus without the ~200-instruction software divide: with
+// m = floor((2^64 - 1) / d), q = mulhi64(x, m) is floor(x / d) or up to 2 less, so r = x - q d needs at most
+// two corrections.  Exact for every x (the reference's randint is `rand % n`, random.cl.inc:37-39).
+struct FastMod {
+  uint64_t d, m;
+};
+__host__ __device__ inline FastMod fast_mod_init(uint64_t d) { return FastMod{d, ~0ull / d}; }
+__device__ __forceinline__ uint64_t fast_mod(uint64_t x, const FastMod& f) {
+  uint64_t r = x - __umul64hi(x, f.m) * f.d;
+  while (r >= f.d) r -= f.d;
+  return r;
+}
+
 // ---------------------------------------------------------------------------- exact division
 // hipcc lowers an IEEE-correct binary32 `x / d` to
 //     d' = div_scale(d), x' = div_scale(x); r0 = rcp(d'); e0 = fma(-d', r0, 1); r = fma(e0, r0, r0);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(MB_BLOCK) void mb_draw_kernel(ammsb_seed* seeds, Mb
   const uint32_t j = blockIdx.x * MB_BLOCK + threadIdx.x;
   if (j >= w.C) return;
   ammsb_seed s = seeds[j];
-  const uint32_t v = (uint32_t)(rng_next(s) % (uint64_t)N);
+  const uint32_t v = (uint32_t)fast_mod(rng_next(s), fast_mod_init(N));
   seeds[j] = s;
   bool valid = v != u;
   if (valid) {
