@@ -6,6 +6,7 @@ reference's lane ownership, summation tree and operation order, most float resul
 bit-identical to the oracle and the tests say so where that holds (FLOAT_TOL stays the stated bar).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -519,3 +520,19 @@ def test_error_behaviour(orc, hip):
     lib = pr.ctx.lib
     assert lib.ammsb_update_phi(None, None, None, None, None, None, None, 1, 1, None, 64, 0, 0, 1, None, None) == -1
     assert lib.ammsb_strerror(-2) == b"HIP runtime error"
+
+
+def test_register_kernels_behind_the_lds_forms():
+    """The LDS-streamed kernels take over the shapes K == wg * kpt; the register-pipelined kernels stay as the general
+    path.  Re-run the phi / beta / perplexity parity cases of this file with the register forms forced (the choice is
+    read once per process, hence the child process)."""
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    env = dict(os.environ, AMMSB_PHI_FORM="r", AMMSB_BETA_FORM="r", AMMSB_PPX_FORM="r")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                          "update_phi or beta_pipeline or perplexity"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
