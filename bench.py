@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: mini-batch edges/s of the SG-MCMC a-MMSB learner loop (+ perplexity-eval ms).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts the N ranks itself
+                                                            as a child `python -m torch.distributed.run ...`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2], "C3"): synthetic a-MMSB graph N = 1M vertices, average degree 32,
@@ -112,13 +113,45 @@ def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
                       "per-thread kernels, OpenMP over nodes/edges, %.1f s)" % (s, n_nodes_big, s, cfg.mini_batch_size, dt)}
 
 
+def launcher_command(gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it was started without a launcher:
+    one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as so:  # a free port, so that back-to-back N = 2, 4, 8 runs never collide
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks_if_needed(args, argv):
+    """`--gpus N` with N > 1 and no RANK in the environment: start the N ranks as a CHILD process (never an exec:
+    nothing here has touched the GPU yet, and nothing will in this parent) and exit with its code.  Under a
+    launcher, WORLD_SIZE must equal --gpus; a mismatch is an error, never a silent one-rank run."""
+    if "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        return
+    if args.gpus <= 1:
+        return
+    cmd = launcher_command(args.gpus, argv)
+    if os.environ.get("AMMSB_BENCH_SPAWN_DRYRUN"):
+        print(json.dumps({"spawn": cmd}))
+        raise SystemExit(0)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    spawn_ranks_if_needed(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     if not torch.cuda.is_available():
@@ -246,7 +279,8 @@ def main():
             "metric": "mini-batch edges/s (SG-MCMC a-MMSB learner loop)",
             "value": edges_done / dt,
             "unit": "edges/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0) if world > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps,
