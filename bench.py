@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--ppx-wg", type=int, default=0)
     ap.add_argument("--host-sampling", action="store_true",
                     help="reference-exact host mini-batch sampler (rand_r) instead of the device sampler")
+    ap.add_argument("--loop", default="auto", choices=["auto", "graph", "eager"],
+                    help="iteration form: captured hipGraphs (auto: one rank + device sampling) or launch by launch")
+    ap.add_argument("--cpp-dropin", type=int, default=1,
+                    help="also time the C++ mcmc::Learner (ammsb_main, a child process) on the same graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="nodes/edges in the CPU-baseline sample")
     ap.add_argument("--ppx-calls", type=int, default=5)
@@ -64,10 +68,41 @@ def pick_wg(K, override, cap):
     return wg
 
 
+def host_cpu_info():
+    """What the CPU baseline ran on: model name, logical CPUs visible, CPUs this process may use (affinity and
+    cgroup quota -- a GPU box hands a container a share of a large host)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"model": model, "nproc": os.cpu_count() or 1, "affinity": affinity, "cgroup_cpu_quota": quota,
+            "usable": usable}
+
+
 def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
     """The reference's CPU path (per-thread kernels, learner.cc:105-114) restated in oracle/, timed on
-    the host cores of this box on a bounded slice of one non-link mini-batch."""
-    import torch
+    the host cores of this box on a bounded slice of one non-link mini-batch: once on every CPU this process
+    may use (OpenMP over nodes/edges), once on one thread."""
+    import ctypes as C
     import oracle_lib as orc
     native = os.path.join(ROOT, "oracle", "libammsb_oracle_native.so")
     try:
@@ -76,12 +111,9 @@ def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
     except Exception:
         lib_path = None
     L = orc.lib(lib_path) if lib_path else orc.lib()
-    import ctypes as C
-    cores = L.orc_num_threads()
+    info = host_cpu_info()
+    cores = info["usable"]
     K, n = cfg.K, cfg.num_node_sample
-    # ~12 ms of one core per (node, edge) pair at K=1024, n=32: aim at roughly 10 s of wall time
-    s = args.cpu_sample or max(256, int(800 * cores * 1024 / max(K, 32)))
-    s = min(s, n_nodes_big - 1)
     rng = np.random.default_rng(1)
     p = orc.make_params(cfg.N, K, n, alpha=np.float32(cfg.alpha))
     pi_h = lrn.pi.host()
@@ -90,27 +122,85 @@ def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
     theta_h = lrn.theta.cpu().numpy().copy()
     tset = ds.training
     slots, bins, pidx = tset.Serialize(), tset.BinsPerBucket(), tset.PrimeIdx()
-    u = int(rng.integers(0, cfg.N))
-    vs = rng.permutation(cfg.N)[:s].astype(np.uint32)
-    nodes = vs.copy()
-    nbrs = rng.integers(0, cfg.N, size=(s, n), dtype=np.uint32)
-    edges = orc.make_edge(np.full(s, u, dtype=np.uint64), vs.astype(np.uint64))
-    seeds = orc.rng_init(s, 42, 43)
-    phi_vec = np.zeros((s, K), dtype=np.float32)
-    grads = np.zeros(2 * K, dtype=np.float32)
-    theta_sum = np.zeros(K, dtype=np.float32)
-    t0 = time.perf_counter()
-    L.orc_update_phi(C.byref(p), beta_h, pi_h.reshape(-1), phi_h, slots, bins, pidx, nodes, nbrs.reshape(-1), s, 1,
-                     seeds, 32, 0, 1, phi_vec.reshape(-1))
-    L.orc_update_pi(C.byref(p), pi_h.reshape(-1), phi_h, phi_vec.reshape(-1), nodes, s, 32, 0)
-    L.orc_sum_theta(theta_h, theta_sum, K)
-    L.orc_beta_grads(C.byref(p), theta_h, theta_sum, beta_h, pi_h.reshape(-1), slots, bins, pidx, edges, s, 32, 0, 0,
-                     grads)
-    L.orc_update_theta(C.byref(p), theta_h, grads, 1, np.float32(1.0), orc.rng_init(K, 44, 45), 1)
-    dt = time.perf_counter() - t0
-    return {"value": s / dt, "unit": "mini-batch edges/s", "cores": int(cores), "kind": "port",
-            "sample": "%d of the %d nodes and %d of the %d edges of one non-link mini-batch (phi+pi+beta, "
-                      "per-thread kernels, OpenMP over nodes/edges, %.1f s)" % (s, n_nodes_big, s, cfg.mini_batch_size, dt)}
+
+    def run(s, threads):
+        """s nodes + s edges of a non-link mini-batch on `threads` OpenMP threads; returns seconds."""
+        L.orc_set_num_threads(threads)
+        u = int(rng.integers(0, cfg.N))
+        vs = rng.permutation(cfg.N)[:s].astype(np.uint32)
+        nbrs = rng.integers(0, cfg.N, size=(s, n), dtype=np.uint32)
+        edges = orc.make_edge(np.full(s, u, dtype=np.uint64), vs.astype(np.uint64))
+        seeds = orc.rng_init(s, 42, 43)
+        phi_vec = np.zeros((s, K), dtype=np.float32)
+        grads = np.zeros(2 * K, dtype=np.float32)
+        theta_sum = np.zeros(K, dtype=np.float32)
+        th = theta_h.copy()
+        t0 = time.perf_counter()
+        L.orc_update_phi(C.byref(p), beta_h, pi_h.reshape(-1), phi_h, slots, bins, pidx, vs, nbrs.reshape(-1), s, 1,
+                         seeds, 32, 0, 1, phi_vec.reshape(-1))
+        L.orc_update_pi(C.byref(p), pi_h.reshape(-1), phi_h, phi_vec.reshape(-1), vs, s, 32, 0)
+        L.orc_sum_theta(th, theta_sum, K)
+        L.orc_beta_grads(C.byref(p), th, theta_sum, beta_h, pi_h.reshape(-1), slots, bins, pidx, edges, s, 32, 0, 0, grads)
+        L.orc_update_theta(C.byref(p), th, grads, 1, np.float32(1.0), orc.rng_init(K, 44, 45), 1)
+        return time.perf_counter() - t0
+    # calibrate on a small slice (one thread), then size both legs to ~8 s and ~4 s of wall time
+    s0 = max(16, min(256, n_nodes_big - 1))
+    per_item = run(s0, 1) / s0                       # seconds per (node, edge) pair on one thread
+    s1 = args.cpu_sample or int(min(n_nodes_big - 1, max(64, 4.0 / per_item)))
+    t1 = run(s1, 1)
+    sN = args.cpu_sample or int(min(n_nodes_big - 1, max(64, 8.0 * cores / per_item)))
+    tN = run(sN, cores)
+    elems = (n + 1) * K  # pi elements read per mini-batch node in update_phi
+    return {"value": sN / tN, "unit": "mini-batch edges/s", "cores": int(cores), "kind": "port",
+            "one_thread_value": s1 / t1, "cpu_model": info["model"], "nproc": info["nproc"],
+            "affinity": info["affinity"], "cgroup_cpu_quota": info["cgroup_cpu_quota"],
+            "omp": "OMP threads = CPUs usable by this process (min of affinity and cgroup quota), no explicit binding "
+                   "(OMP_PROC_BIND unset), schedule(dynamic) over nodes / edges",
+            "ns_per_pi_element_one_thread": round(t1 / (s1 * elems) * 1e9, 2),
+            "sample": "%d of the %d nodes and %d of the %d edges of one non-link mini-batch on %d threads in %.1f s "
+                      "(phi+pi+beta, the reference's per-thread CPU kernels restated in oracle/, -O3 -march=native "
+                      "-ffp-contract=off); one thread: %d nodes+edges in %.1f s"
+                      % (sN, n_nodes_big, sN, cfg.mini_batch_size, cores, tN, s1, t1)}
+
+
+def cpp_dropin(args, hostlib, N, K, m, n, wg, edges, note):
+    """north_star's host: the C++ mcmc::Learner behind the reference's command line (host/main.cc), run as a child
+    process on the same graph (gzip data-set file, main.cc:110-124), for each loop form.  Its PrintStats line gives
+    the mini-batch edge rate of Learner::Run alone (perplexity evaluations excluded)."""
+    import re
+    import tempfile
+    exe = os.path.join(ROOT, "mcmc-ammsb-gpu_amd", "ammsb_main")
+    if not os.path.exists(exe):
+        return {"error": "ammsb_main not built"}
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "g.bin.gz")
+        hostlib.dump_dataset(f, N, 0.01, edges)
+        iters = max(args.steps, 200)
+        for name, flags in (("graph", ["--async", "1", "--graph", "1"]), ("async", ["--async", "1"]), ("sync", [])):
+            cmd = [exe, "--load-data", "1", "--load-file", f, "-k", str(K), "-m", str(m), "-n", str(n), "-x", str(iters),
+                   "-i", str(iters), "--phi-wg", str(wg), "--beta-wg", str(wg), "--ppx-wg", str(wg),
+                   "--device-sampling", "1"] + flags
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            except subprocess.TimeoutExpired:
+                out[name] = {"error": "timeout"}
+                continue
+            text = r.stdout + r.stderr
+            mt = re.search(r"MINI-BATCH EDGES: (\d+) \(([0-9.eE+-]+) edges/s\)", text)
+            tt = re.search(r"TOTAL\s*: ([0-9.eE+-]+)", text)
+            px = re.findall(r"ppx\[\s*(\d+)\]\s*=?\s*([0-9.eE+-]+)", text)
+            if r.returncode != 0 or not mt:
+                out[name] = {"error": "rc=%d" % r.returncode, "tail": text[-300:]}
+                continue
+            out[name] = {"edges_per_s": float(mt.group(2)), "mini_batch_edges": int(mt.group(1)), "iterations": iters,
+                         "total_s": float(tt.group(1)) if tt else None,
+                         "perplexity": float(px[-1][1]) if px else None,
+                         "process_s": round(time.perf_counter() - t0, 1)}
+            note("cpp drop-in (%s): %.3e edges/s" % (name, out[name]["edges_per_s"]))
+    out["command"] = "ammsb_main --load-data 1 --load-file <graph> -k %d -m %d -n %d --device-sampling 1 [--async 1 [--graph 1]]" % (K, m, n)
+    return out
 
 
 def launcher_command(gpus, argv, port=None):
@@ -190,14 +280,16 @@ def main():
     note("graph: %d edges" % edges.size)
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.01, rand_seed=1)
     note("training / held-out sets built")
+    use_graph = args.loop == "graph" or (args.loop == "auto" and world == 1 and not args.host_sampling)
     cfg = Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, strategy="Node",
                                    phi_wg_size=pick_wg(K, args.phi_wg, 16),   # K=1024 -> 64: the LDS-streamed kernel
                                    beta_wg_size=pick_wg(K, args.beta_wg, 16),  # K=1024 -> 64: the LDS-streamed kernel
                                    ppx_wg_size=pick_wg(K, args.ppx_wg, 16),   # K=1024 -> 64
-                                   device_sampling=not args.host_sampling)
+                                   device_sampling=not args.host_sampling,
+                                   graph_launch=use_graph, graph_timestamps=use_graph)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
-    note("learner ready")
+    note("learner ready (%s loop)" % ("captured-graph" if lrn.loop is not None else "eager"))
 
     def sync():
         lrn.drain()
@@ -217,8 +309,10 @@ def main():
     # ---- warm-up, then EXACTLY --steps timed iterations
     lrn.Run(args.warmup)
     sync()
-    # HIP-event timing of the dominant kernel (update_phi) on its launch stream, inside the timed region
     phi = lrn.phiUpdater
+    # Device time of the dominant kernel (update_phi) inside the timed region, per launch.  Eager loop: HIP events
+    # on the launch stream around each launch.  Captured-graph loop: device wall-clock stamps written by two
+    # one-thread kernels around update_phi inside every graph (AMMSB_LOOP_TIMESTAMPS).
     ev = []
     orig = phi.update_phi
 
@@ -229,7 +323,10 @@ def main():
         b.record(torch.cuda.current_stream())
         ev.append((a, b, nn, max(0, min(hi, min(nn, 65535)) - lo)))
 
-    phi.update_phi = timed_update_phi
+    if lrn.loop is None:
+        phi.update_phi = timed_update_phi
+    lrn.step_log = []  # (n_edges, n_nodes) of every step of the timed region (both loops append)
+    first_step = phi.count_calls + 1
     edges_before = lrn.edges_done
     sync()
     t0 = time.perf_counter()
@@ -243,20 +340,42 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     edges_done = lrn.edges_done - edges_before  # identical on every rank: the whole job's mini-batch edges
+    step_log = list(lrn.step_log)
+    lrn.step_log = None
 
-    # roofline of update_phi over the big (non-link) launches of the timed region
-    big = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev if nn > m // 2]
+    # per-launch records of update_phi: (seconds, nodes in the mini-batch, nodes this rank's launch processed)
+    step_classes = None
+    if lrn.loop is not None:
+        kept = min(args.steps, 8192)
+        b_ns, e_ns = lrn.loop.timestamps(first_step + args.steps - kept, kept)
+        log = step_log[-kept:]
+        launches = [((e_ns[i] - b_ns[i]) * 1e-9, log[i][1], min(log[i][1], 65535)) for i in range(kept)]
+        # a step's device time = from its update_phi start to the next step's (the sampling branch of the next
+        # mini-batch runs inside it); the last step of the window has no successor and is left out
+        dur = (b_ns[1:] - b_ns[:-1]) * 1e-6
+        non = np.array([log[i][0] == m for i in range(kept - 1)], dtype=bool)
+        step_classes = {
+            "nonlink": {"steps": int(non.sum()), "ms_per_step": float(dur[non].mean()) if non.any() else None,
+                        "edges_per_step": m},
+            "link": {"steps": int((~non).sum()), "ms_per_step": float(dur[~non].mean()) if (~non).any() else None,
+                     "edges_per_step": float(np.mean([log[i][0] for i in range(kept - 1) if not non[i]])) if (~non).any() else None},
+            "source": "device wall-clock stamps at the start of consecutive steps' update_phi",
+        }
+    else:
+        launches = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev]
+    big = [(t, nn, g) for t, nn, g in launches if nn > m // 2]
     roofline = None
     if big:
         per_node = 4 * K * (n + 2) + 68 * n + 8  # algorithmic bytes of update_phi per mini-batch node
-        nodes_per_launch = float(np.mean([g for _, _, g in big]))  # nodes this rank's launch processed
+        nodes_per_launch = float(np.mean([g if nn <= 65535 else nn * (g / 65535.0) for _, nn, g in big]))
         avg_s = float(np.mean([t for t, _, _ in big]))
         achieved = per_node * nodes_per_launch / avg_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "phi_traffic.json")
         if args.workload == "C3" and world == 1 and os.path.exists(tpath):  # the PMC passes were taken on this case
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/phi_traffic.json (stored rocprofv3 --pmc passes of this workload, not measured in this run)"
             except Exception:
                 traffic = None
         wgp = cfg.phi_wg_size
@@ -264,8 +383,17 @@ def main():
         kname = ("update_phi_lds_kernel<%d, %d>" % (K // wgp, wgp // 64)) if lds_form else "update_phi_kernel"  # ammsb_phi.hip dispatch
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "launches": len(big),
-                    "bytes_per_launch": int(per_node * nodes_per_launch)}
+                    "bytes_per_launch": int(per_node * nodes_per_launch),
+                    "timer": "device wall-clock stamps inside the captured graphs" if lrn.loop is not None
+                             else "HIP events on the launch stream"}
+        if step_classes and step_classes["nonlink"]["ms_per_step"]:
+            # step-level: algorithmic bytes of ALL kernels of a non-link iteration / its device time
+            step_bytes = (m + 1) * (4 * K * (n + 4) + 68 * n + 8) + m * (8 * K + 72) + 24 * K
+            st = step_classes["nonlink"]["ms_per_step"] * 1e-3
+            roofline["step"] = {"bytes_per_nonlink_step": int(step_bytes), "achieved": round(step_bytes / st / 1e9, 1),
+                                "frac": round(step_bytes / st / 1e9 / 8000.0, 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -273,6 +401,17 @@ def main():
             cpu = cpu_baseline(args, lrn, cfg, ds, m + 1)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
             cpu = {"value": None, "unit": "mini-batch edges/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    final_ppx = lrn.HeldoutPerplexity()
+    graphs = lrn.loop is not None
+    lrn.close()
+    cpp = None
+    if rank == 0 and world == 1 and args.cpp_dropin and args.workload in ("C1", "C2", "C3"):
+        del lrn
+        torch.cuda.empty_cache()
+        try:
+            cpp = cpp_dropin(args, hostlib, N, K, m, n, cfg.phi_wg_size, edges, note)
+        except Exception as e:
+            cpp = {"error": repr(e)}
 
     if rank == 0:
         out = {
@@ -293,20 +432,26 @@ def main():
                                    % (args.workload, N, deg, K, m, n),
                        "E": int(ds.E), "heldout_edges": int(ds.heldout_edges.size),
                        "phi_wg": cfg.phi_wg_size, "beta_wg": cfg.beta_wg_size, "ppx_wg": cfg.ppx_wg_size,
-                       "sampling": "host(rand_r)" if args.host_sampling else "device",
+                       "sampling": "host(rand_r): the reference's stream" if args.host_sampling else
+                                   "device: same distribution as sample.cc, NOT its rand_r stream (same seed does not "
+                                   "reproduce a reference trajectory; --host-sampling does)",
+                       "loop": "captured hipGraphs (one launch per iteration)" if graphs else "eager (one launch per kernel)",
+                       "host": "python (ctypes -> C ABI); see cpp_dropin for the C++ mcmc::Learner",
                        "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
                        "phi_split": None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
                                                                  groups_per_block=lrn.cc, chunks=lrn.nch)},
             "host_enqueue_ms_per_step": t_enq * 1e3 / args.steps,
+            "step_classes": step_classes,
             "ppx_eval_ms": ppx_ms,
             "perplexity": ppx,
+            "perplexity_after": final_ppx,
             "mini_batch_edges": int(edges_done),
             "setup_s": round(setup_s, 1),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpp_dropin": cpp,
         }
         print(json.dumps(out))
-    lrn.close()
     if world > 1:
         dist.destroy_process_group()
 

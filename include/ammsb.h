@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AMMSB_VERSION 100
+#define AMMSB_VERSION 200
 
 enum {
   AMMSB_OK = 0,
@@ -97,6 +97,10 @@ int ammsb_ctx_params(const ammsb_ctx* ctx, ammsb_params* out);
 
 /* RandomInit, random.cc:31-43: seeds[i] = {sx + i, sy + i}.  Replaces OpenClRandomFactory::CreateRandom. */
 int ammsb_rng_init(ammsb_ctx* ctx, ammsb_seed* seeds, uint64_t n, uint64_t sx, uint64_t sy, void* stream);
+/* Streams for consumers the reference does not have (the device mini-batch sampler): seeds[i] = {mix(sx + 2i),
+ * mix(sy + 2i + 1)}, mix = the SplitMix64 finaliser.  The reference layout above gives neighbouring streams nearly
+ * identical states whose first xorshift128+ outputs are strongly correlated across streams. */
+int ammsb_rng_init_mixed(ammsb_ctx* ctx, ammsb_seed* seeds, uint64_t n, uint64_t sx, uint64_t sy, void* stream);
 
 /* Set_HasEdge over a key list (the `find` kernel of cuckoo-test.cc:45-53). out[i] = 0/1. */
 int ammsb_set_has(ammsb_ctx* ctx, const ammsb_set* set, const uint64_t* keys, uint64_t n, uint8_t* out,
@@ -165,19 +169,99 @@ int ammsb_minibatch_link(ammsb_ctx* ctx, const uint64_t* csr_offsets, const uint
                          uint32_t n, uint64_t* edges_out, uint32_t* nodes_out, void* stream);
 
 /* number of candidate draws (= RNG streams, = workspace entries) ammsb_minibatch_nonlink needs for
- * m distinct non-links out of N vertices; 0 if N is too small for m (needs N >= 2m) */
+ * m distinct non-links out of N vertices when up to `excluded` vertices are invalid partners of u (u itself and
+ * its neighbours in the training and held-out graphs): enough draws for m + excluded distinct values plus a
+ * margin of 8 % + 1024.  0 if N is too small (needs N >= 2m and the target below 0.95 N).  Size the streams
+ * and the workspace for the largest `excluded` of the graph (capacity), and pass the per-vertex value
+ * (<= capacity) to each call.  ammsb_minibatch_candidates(N, m) = ..._for(N, m, 0). */
 uint32_t ammsb_minibatch_candidates(uint64_t N, uint32_t m);
-/* bytes of workspace for that many candidates */
-uint64_t ammsb_minibatch_workspace_bytes(uint32_t n_candidates);
+uint32_t ammsb_minibatch_candidates_for(uint64_t N, uint32_t m, uint64_t excluded);
+/* bytes of workspace for a capacity of that many candidates.  The caller fills the workspace with 0xFF bytes ONCE
+ * after allocating it; every ammsb_minibatch_nonlink call leaves it in that state again (no memset per call). */
+uint64_t ammsb_minibatch_workspace_bytes(uint32_t capacity);
 
 /* sampleNodeNonLink: m distinct v != u with (u,v) in neither set, in candidate order (candidate j =
- * one draw from stream j, kept if valid and the first occurrence of its v).  edges_out[m],
- * nodes_out[m+1] = {u, v_0, ...}; count_out[0] = number of distinct valid candidates found (>= m
- * unless the draw was exceptionally unlucky, in which case the tail repeats earlier entries and
- * count_out[0] < m tells the caller).  heldout_set may be NULL. */
-int ammsb_minibatch_nonlink(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_candidates, uint32_t u, uint32_t m,
-                            const ammsb_set* training_set, const ammsb_set* heldout_set, void* workspace,
+ * one draw from stream j, j < n_candidates, kept if valid and the first occurrence of its v).  `capacity` is
+ * the candidate count seeds / workspace were sized for (n_candidates <= capacity, both multiples of 256).
+ * edges_out[m], nodes_out[m+1] = {u, v_0, ...}.  count_out: TWO words -- [0] = number of distinct valid
+ * candidates found by this call, [1] += 1 whenever that number is below m (a sticky shortfall counter the caller
+ * clears and checks at its synchronisation points: a short mini-batch repeats earlier entries to stay
+ * memory-safe and is NOT a valid sample).  With n_candidates from ammsb_minibatch_candidates_for(N, m,
+ * 1 + deg_training(u) + deg_heldout(u)) a shortfall needs an astronomically unlucky draw.  heldout_set may be NULL. */
+int ammsb_minibatch_nonlink(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_candidates, uint32_t capacity, uint32_t u,
+                            uint32_t m, const ammsb_set* training_set, const ammsb_set* heldout_set, void* workspace,
                             uint64_t* edges_out, uint32_t* nodes_out, uint32_t* count_out, void* stream);
+
+/* ---- whole iterations as captured hipGraphs (new; replaces the launch-then-Finish discipline of
+ *      learner.cc:237-242, phi.cc:755-761, beta.cc:339-383 where the iteration is launch-latency-bound) ----
+ * One ammsb_loop owns eight small graphs: [update_phi, update_pi, beta gradient, theta/beta step] of THIS step
+ * (main stream) and [mini-batch + neighbour sampling of the NEXT step] (sampler stream), each specialised by
+ * (link batch?, buffer parity); a learner iteration with device-side mini-batch sampling is one launch of each.  The per-step scalars (sizes, eps_t, weight, u) are read by the kernels from device-resident
+ * descriptors the loop uploads a chunk at a time, so a step costs the host two hipGraphLaunch calls and two events.
+ * Same kernels, same arguments, same per-stream order as the eager entry points above: the trajectory is
+ * bit-identical to calling them one by one.  The caller keeps choosing (link?, u) per mini-batch, as with the
+ * eager sampler entry points. */
+typedef struct ammsb_loop ammsb_loop;
+
+#define AMMSB_LOOP_TIMESTAMPS 1u /* update_phi / update_pi note the device time at which their first block starts */
+#define AMMSB_LOOP_SERIAL 2u     /* one graph per step on one stream (sampling chain in line) instead of two streams */
+
+typedef struct {
+  /* model state (learner.cc:80-91) */
+  float* theta;
+  float* beta;
+  const ammsb_rpm* pi;
+  float* phi_sum;
+  const ammsb_set* training_set;
+  const ammsb_set* heldout_set; /* may be NULL */
+  /* PhiUpdater state: streams [min(max_nodes, 65535) * phi_wg], phi_vec [max_nodes, K] (phi.cc:620-629) */
+  ammsb_seed* phi_seeds;
+  float* phi_vec;
+  uint32_t phi_wg, phi_flags;
+  /* BetaUpdater state: streams [K], grads [2K] */
+  ammsb_seed* beta_seeds;
+  float* grads;
+  uint32_t beta_wg, beta_flags;
+  /* the two Sample buffers (sample.h:51-92): edges [max_edges], nodes [max_nodes], neighbour sampler output
+   * [max_nodes, n], table [max_nodes, 2n] and streams, per parity */
+  uint64_t* edges[2];
+  uint32_t* nodes[2];
+  uint32_t* neighbors[2];
+  uint32_t* nbr_table[2];
+  ammsb_seed* nbr_seeds[2];
+  uint32_t nbr_wg;
+  /* device mini-batch sampler: training CSR, candidate streams / workspace of capacity mb_candidates, count[2] */
+  const uint64_t* csr_offsets;
+  const uint32_t* csr_targets;
+  ammsb_seed* mb_seeds;
+  uint32_t mb_candidates;
+  void* mb_workspace;
+  uint32_t* mb_count;
+  uint32_t mini_batch;  /* m */
+  uint32_t max_fan_out; /* largest training degree: link batches are launched for this size */
+  uint32_t flags;       /* AMMSB_LOOP_* */
+} ammsb_loop_config;
+
+/* one mini-batch choice of the "Node" strategy family (sample.cc:249-303): link = all n = deg(u) training edges
+ * of u (n > 0); non-link = m non-links of u drawn from n_candidates candidate streams */
+typedef struct {
+  uint32_t link, u, n, n_candidates;
+} ammsb_mb_choice;
+
+/* Captures the graphs; every buffer in cfg must stay valid (and keep its address) until ammsb_loop_destroy. */
+int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, ammsb_loop** out);
+int ammsb_loop_destroy(ammsb_loop* loop);
+/* Enqueue n_steps iterations behind the work already queued on `stream` (and make `stream` wait for them).
+ * `pending` describes the mini-batch that already sits in buffer pair `parity` (sampled + neighbour-sampled
+ * by the eager entry points or by an earlier run); next[i] is the mini-batch sampled DURING step i and consumed
+ * by step i + 1, so after the call next[n_steps - 1] is pending in pair parity ^ (n_steps & 1).  Step i uses
+ * step_count = first_step_count + i for eps_t.  Does not synchronise. */
+int ammsb_loop_run(ammsb_loop* loop, const ammsb_mb_choice* pending, const ammsb_mb_choice* next, uint32_t n_steps,
+                   uint32_t first_step_count, uint32_t parity, void* stream);
+/* (AMMSB_LOOP_TIMESTAMPS) device time in ns at which update_phi of steps first_step .. first_step + n_steps - 1
+ * began, and at which the kernel after it (update_pi) began -- update_phi's duration plus one kernel boundary: a
+ * slight over-estimate, never an under-estimate.  The last 8192 steps are kept.  Synchronises. */
+int ammsb_loop_timestamps(ammsb_loop* loop, uint32_t first_step, uint32_t n_steps, double* begin_ns, double* end_ns);
 
 /* ---- wg_* primitives (test entry points; kernels of algorithm/{sum,normalize,sort}.cc) ---- */
 /* WG_SUM_KERNEL_TT, sum.cc:44-52: out[r] = WG_SUM(in + r*len, len) with `wg` lanes (any wg in [1,1024]) */

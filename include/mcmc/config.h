@@ -70,6 +70,9 @@ struct Config {
   // device_sampling, a two-stream loop ordered by events instead of host joins.  Results are identical; the
   // per-kernel times of PrintStats stay zero.
   bool async_launch;
+  // new: with async_launch + device_sampling, enqueue whole iterations as captured hipGraphs (ammsb_loop,
+  // include/ammsb.h): one hipGraphLaunch per iteration instead of a dozen kernel launches.  Results are identical.
+  bool graph_launch;
   ulong2 device_sampling_seed;  // new: streams of the device sampler's candidate draws
   uint64_t device_sampling_host_seed;  // new: host generator choosing (link?, u) per mini-batch
   // new: rand_r seeds of the two Sample buffers.  The reference takes them from the process-global

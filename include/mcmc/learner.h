@@ -5,6 +5,7 @@
 #include <signal.h>
 
 #include <future>
+#include <map>
 #include <istream>
 #include <memory>
 #include <ostream>
@@ -39,8 +40,14 @@ class Learner {
   Float DoSampleDevice(Sample* sample);  // Config::device_sampling: csrc/ammsb_minibatch.hip instead of sample.cc
   bool SerializeDeviceSampler(std::ostream* out);
   void RunAsync(uint32_t max_iters, sig_atomic_t* signaled);  // Config::async_launch + device_sampling
+  void RunGraph(uint32_t max_iters, sig_atomic_t* signaled);  // Config::graph_launch: iterations as captured graphs
+  ammsb_mb_choice ChooseDevice();                             // the next mini-batch: (link?, u, deg(u), candidates)
+  Float EnqueueDevice(Sample* sample, const ammsb_mb_choice& choice);
   void DrainAsync();
   bool ParseDeviceSampler(std::istream* in);
+  uint32_t CandidatesFor(uint64_t u);  // candidate draws of a non-link mini-batch of vertex u
+  uint32_t CandidatesForExcluded(uint32_t excluded);
+  void CheckDeviceSampler();           // throws if a mini-batch came up short since the last check
 
   const Config& cfg_;
   clcuda::Queue queue_;
@@ -64,6 +71,8 @@ class Learner {
   std::unique_ptr<clcuda::Buffer<uint64_t>> csr_offsets_;
   std::unique_ptr<clcuda::Buffer<Vertex>> csr_targets_;
   std::vector<uint32_t> degree_;
+  std::vector<uint32_t> excluded_;  // 1 + training degree + held-out link degree
+  std::map<uint32_t, uint32_t> cand_cache_;
   uint32_t candidates_ = 0;
   std::unique_ptr<random::OpenClRandom> mb_rand_;
   std::unique_ptr<clcuda::Buffer<uint8_t>> mb_workspace_;
@@ -78,6 +87,8 @@ class Learner {
   bool sampler_valid_ = false;
   bool enqueued_[2] = {false, false};
   Float weights_[2] = {0, 0};
+  ammsb_mb_choice choice_[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // what sits in each sample's buffers (device sampling)
+  ammsb_loop* loop_ = nullptr;
   std::unique_ptr<Sample> samples_[2];  // MCMC_SAMPLE_PARALLEL (CMakeLists.txt:42, default ON)
   std::future<Float> futures_[2];
   int phase_;

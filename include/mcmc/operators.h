@@ -131,6 +131,8 @@ class NeighborSampler {
   clcuda::Buffer<Vertex>& GetData() { return data_; }
   uint32_t HashCapacityPerSample() { return capacity_; }
   uint32_t DataSizePerSample() { return n_; }
+  random::OpenClRandom& Rand() { return rand_; }  // stream states / work-group size, for the captured-graph loop
+  uint32_t Local() const { return local_; }
   bool Serialize(std::ostream* out);  // sample.h:30-36
   bool Parse(std::istream* in);
 
@@ -171,6 +173,10 @@ class PhiUpdater {
   uint64_t UpdatePhiTime() const { return t_update_phi_; }  // ns of device time (hip events)
   uint64_t UpdatePiTime() const { return t_update_pi_; }
   clcuda::Buffer<Float>& GetPhiVec() { return phi_vec_; }
+  random::OpenClRandom& Rand() { return rand_; }  // for the captured-graph loop (ammsb_loop)
+  uint32_t& CountCalls() { return count_calls_; }
+  uint32_t Local() const { return local_; }
+  uint32_t Flags() const { return flags_; }
   bool Serialize(std::ostream* out);  // phi.cc:765-784
   bool Parse(std::istream* in);
 
@@ -198,6 +204,9 @@ class BetaUpdater {
   void operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale);
   clcuda::Buffer<Float>& GetGrads() { return grads_; }
   clcuda::Buffer<Float>& GetThetaSum();  // beta.h:27: as of the last operator()
+  random::OpenClRandom& Rand() { return rand_; }  // for the captured-graph loop (ammsb_loop)
+  uint32_t& CountCalls() { return count_calls_; }
+  uint32_t Local() const { return local_; }
   // device time in ns.  The reference's five stages (beta.h:30-34) are two launches here: theta_sum +
   // partial gradients + their sum are one call, update_theta + theta->beta normalisation the other.
   uint64_t ThetaSumTime() const { return 0; }

@@ -41,6 +41,25 @@ class PpxSums(C.Structure):
 _vp, _u32, _u64, _f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
 _P = C.POINTER
 
+LOOP_TIMESTAMPS = 1
+
+
+class LoopConfig(C.Structure):  # ammsb_loop_config
+    _fields_ = [("theta", _vp), ("beta", _vp), ("pi", _P(Rpm)), ("phi_sum", _vp),
+                ("training_set", _P(SetDesc)), ("heldout_set", _P(SetDesc)),
+                ("phi_seeds", _vp), ("phi_vec", _vp), ("phi_wg", _u32), ("phi_flags", _u32),
+                ("beta_seeds", _vp), ("grads", _vp), ("beta_wg", _u32), ("beta_flags", _u32),
+                ("edges", _vp * 2), ("nodes", _vp * 2), ("neighbors", _vp * 2), ("nbr_table", _vp * 2),
+                ("nbr_seeds", _vp * 2), ("nbr_wg", _u32),
+                ("csr_offsets", _vp), ("csr_targets", _vp), ("mb_seeds", _vp), ("mb_candidates", _u32),
+                ("mb_workspace", _vp), ("mb_count", _vp), ("mini_batch", _u32), ("max_fan_out", _u32),
+                ("flags", _u32)]
+
+
+class MbChoice(C.Structure):  # ammsb_mb_choice
+    _fields_ = [("link", _u32), ("u", _u32), ("n", _u32), ("n_candidates", _u32)]
+
+
 # name -> argtypes (all return int unless listed in _OTHER_RES)
 SIGNATURES = {
     "ammsb_version": [],
@@ -53,6 +72,7 @@ SIGNATURES = {
     "ammsb_theta_sum": [_vp, _vp, _vp],
     "ammsb_ctx_params": [_vp, _P(Params)],
     "ammsb_rng_init": [_vp, _vp, _u64, _u64, _u64, _vp],
+    "ammsb_rng_init_mixed": [_vp, _vp, _u64, _u64, _u64, _vp],
     "ammsb_set_has": [_vp, _P(SetDesc), _vp, _u64, _vp, _vp],
     "ammsb_pi_init_gamma": [_vp, _P(Rpm), _vp, _f32, _f32, _vp, _vp],
     "ammsb_sample_neighbors": [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
@@ -65,8 +85,13 @@ SIGNATURES = {
     "ammsb_perplexity": [_vp, _vp, _P(Rpm), _P(SetDesc), _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "ammsb_minibatch_link": [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "ammsb_minibatch_candidates": [_u64, _u32],
+    "ammsb_minibatch_candidates_for": [_u64, _u32, _u64],
     "ammsb_minibatch_workspace_bytes": [_u32],
-    "ammsb_minibatch_nonlink": [_vp, _vp, _u32, _u32, _u32, _P(SetDesc), _P(SetDesc), _vp, _vp, _vp, _vp, _vp],
+    "ammsb_minibatch_nonlink": [_vp, _vp, _u32, _u32, _u32, _u32, _P(SetDesc), _P(SetDesc), _vp, _vp, _vp, _vp, _vp],
+    "ammsb_loop_create": [_vp, _P(LoopConfig), _P(_vp)],
+    "ammsb_loop_destroy": [_vp],
+    "ammsb_loop_run": [_vp, _P(MbChoice), _P(MbChoice), _u32, _u32, _u32, _vp],
+    "ammsb_loop_timestamps": [_vp, _u32, _u32, _P(C.c_double), _P(C.c_double)],
     "ammsb_wg_sum_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "ammsb_wg_sum_u32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "ammsb_wg_normalize_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
@@ -78,7 +103,8 @@ SIGNATURES = {
     "ammsb_rpm_fetch": [_vp, _P(Rpm), _u64, _u64, _vp, _vp],
 }
 _OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_eps_t": C.c_float,
-              "ammsb_minibatch_candidates": C.c_uint32, "ammsb_minibatch_workspace_bytes": C.c_uint64}
+              "ammsb_minibatch_candidates": C.c_uint32, "ammsb_minibatch_candidates_for": C.c_uint32,
+              "ammsb_minibatch_workspace_bytes": C.c_uint64}
 
 _lib = None
 

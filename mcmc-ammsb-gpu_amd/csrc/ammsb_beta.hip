@@ -17,6 +17,7 @@
 
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
+#include "ammsb_step.h"
 
 using namespace ammsb;
 
@@ -32,15 +33,30 @@ struct BetaArgs {
   float* theta_sum;  // [K]
   uint32_t edge_begin, edge_end, P, K;
   float epsilon;
+  const ammsb_step_desc* desc;  // non-null (captured graph): edges [0, desc->n_edges), P = min(n_edges, P)
 };
+
+struct BetaStep {
+  uint32_t edge_begin, edge_end, P;
+};
+__device__ __forceinline__ BetaStep beta_step(const BetaArgs& a) {
+  BetaStep st = {a.edge_begin, a.edge_end, a.P};
+  if (a.desc) {
+    st.edge_begin = 0;
+    st.edge_end = a.desc->n_edges;
+    st.P = st.edge_end < a.P ? st.edge_end : a.P;
+  }
+  return st;
+}
 
 template <int L, int KPT>
 __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaArgs a) {
   using Grp = Group<L>;
   __shared__ float aux[Grp::AUX];
   const int l = Grp::lane();
+  const BetaStep st = beta_step(a);
   const uint32_t gs = blockIdx.x * Grp::PER_BLOCK + Grp::slot();  // partial-row slot
-  const bool live = gs < a.P;
+  const bool live = gs < st.P;
   const uint32_t K = a.K;
   const float EPS = a.epsilon;
 
@@ -68,8 +84,8 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
 #pragma unroll
   for (int j = 0; j < KPT; ++j) acc0[j] = acc1[j] = 0.0f;
 
-  const uint32_t n_edges = a.edge_end - a.edge_begin;
-  const uint32_t trips = (n_edges + a.P - 1) / a.P;  // uniform
+  const uint32_t n_edges = st.edge_end - st.edge_begin;
+  const uint32_t trips = (n_edges + st.P - 1) / st.P;  // uniform
   int phase = 0;
 
   // Software pipeline.  A slot walks edges e(t) = edge_begin + gs + t * P.  Two dependent latencies sit
@@ -83,9 +99,9 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   const int kl = threadIdx.x & (W - 1);  // lane within the key batch
   const int wave_lane = threadIdx.x & 63;
   auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
-    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + kl) * a.P;
-    const bool ok = live && (tb + kl) < trips && e < a.edge_end;
-    const unsigned long long edge = a.edges[ok ? e : a.edge_begin];  // an exhausted trip shadows the first edge
+    const uint64_t e = (uint64_t)st.edge_begin + gs + (uint64_t)(tb + kl) * st.P;
+    const bool ok = live && (tb + kl) < trips && e < st.edge_end;
+    const unsigned long long edge = a.edges[ok ? e : st.edge_begin];  // an exhausted trip shadows the first edge
     const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
     *ymask = __ballot(set_has(a.set, make_edge(u, v)));  // bit = lane of the wave
     return edge;
@@ -98,8 +114,8 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   bool link[3] = {false, false, false};
   bool have[3] = {false, false, false};
   auto fetch = [&](int b, uint32_t t) {
-    const uint64_t e_raw = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
-    have[b] = live && t < trips && e_raw < a.edge_end;
+    const uint64_t e_raw = (uint64_t)st.edge_begin + gs + (uint64_t)t * st.P;
+    have[b] = live && t < trips && e_raw < st.edge_end;
     const uint32_t rel = t - tb;  // 0 .. 2W-1 by construction
     const bool first = rel < (uint32_t)W;
     const uint32_t src = first ? rel : rel - W;                 // lane of the group's key batch
@@ -210,7 +226,9 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   const int tid = threadIdx.x, wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
   char* wave_smem = smem + wv * (D * KW * sizeof(float));
   float* ring = reinterpret_cast<float*>(wave_smem);
-  const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks
+  const BetaStep st = beta_step(a);
+  const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks (at least P with a descriptor)
+  if (gs >= st.P) return;          // block-uniform
   const float EPS = a.epsilon;
 
   f32x2 bk[HP], d0n[HP], d1l[HP], noo[HP];
@@ -239,16 +257,16 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   for (int p = 0; p < HP; ++p) acc0[p] = acc1[p] = f32x2{0.0f, 0.0f};
 
   // edges of this slot: e(t) = edge_begin + gs + t * P, t < trips
-  const uint32_t n_edges = a.edge_end - a.edge_begin;
-  const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // block-uniform
+  const uint32_t n_edges = st.edge_end - st.edge_begin;
+  const uint32_t trips = gs < n_edges ? (n_edges - gs + st.P - 1) / st.P : 0;  // block-uniform
   int phase = 0;
 
   // keys and link bits: lane i of every wave holds trip tb + i (and tb + 64 + i in the second window), probed one
   // whole window ahead -- see the register kernel
   auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
     const bool ok = tb + ln < trips;
-    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + ln) * a.P;
-    const unsigned long long edge = a.edges[ok ? e : a.edge_begin];
+    const uint64_t e = (uint64_t)st.edge_begin + gs + (uint64_t)(tb + ln) * st.P;
+    const unsigned long long edge = a.edges[ok ? e : st.edge_begin];
     const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
     *ymask = __ballot(set_has(a.set, make_edge(u, v)));
     return edge;
@@ -406,8 +424,9 @@ int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
 // block (2K/16 blocks, so the whole chip takes part): row-lane r adds rows r, r+16, ... ascending,
 // then the 16 lane sums are added by the halving tree r += r+8, +4, +2, +1.
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, uint32_t P, uint32_t cols,
-                                                            float* out) {
+                                                            float* out, const ammsb_step_desc* desc) {
   __shared__ float red[16][17];
+  if (desc) P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)
   const uint32_t cl = threadIdx.x & 15, r = threadIdx.x >> 4;
   const uint32_t c = blockIdx.x * 16 + cl;
   float s = 0.0f;
@@ -426,8 +445,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials
 // 128 row-lanes; row-lane r adds rows r, r + 128, ... ascending (all loads independent, in flight
 // together), then the halving tree r += r + 64, ..., + 1.  2K/8 blocks.
 __global__ __launch_bounds__(256) void sum_partials8_kernel(const float* partials, uint32_t P, uint32_t cols,
-                                                             float* out) {
+                                                             float* out, const ammsb_step_desc* desc) {
   __shared__ float4 red[128][2];
+  if (desc) P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)
   const uint32_t h = threadIdx.x & 1, r = threadIdx.x >> 1;
   const uint32_t c = blockIdx.x * 8 + 4 * h;
   float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -456,22 +476,17 @@ __global__ __launch_bounds__(256) void sum_partials8_kernel(const float* partial
 }
 
 // update_theta (beta.cc:51-82) + beta = pair-normalised theta (beta.cc:376-383; Normalizer slice 2,
-// wg 1: lsum = (0 + t0) + t1).  Thread k owns stream k: r0 for theta[k,0], then r1 for theta[k,1].
-__global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* beta, const float* grads,
-                                                           ammsb_seed* seeds, uint32_t K, float eps_t, float scale,
-                                                           float eta0, float eta1, uint32_t noise_on) {
-  __shared__ ZigTables zig;
-  zig_load(&zig);
-  __syncthreads();
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
+// wg 1: lsum = (0 + t0) + t1) for component k: stream k draws r0 for theta[k,0], then r1 for theta[k,1].
+__device__ __forceinline__ void theta_step(uint32_t k, float g0, float g1, float* theta, float* beta, ammsb_seed* seeds,
+                                           float eps_t, float scale, float eta0, float eta1, uint32_t noise_on,
+                                           const ZigTables* zig) {
   ammsb_seed rs = seeds[k];
   const float half = eps_t / 2.0f;
   float th[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    const float r = noise_on ? rng_normal(rs, &zig) : 1.0f;
-    const float g = grads[2 * k + c];
+    const float r = noise_on ? rng_normal(rs, zig) : 1.0f;
+    const float g = c == 0 ? g0 : g1;
     const float t = theta[2 * k + c];
     const float eta = c == 0 ? eta0 : eta1;
     const float ep = eps_t * t;
@@ -493,6 +508,78 @@ __global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* b
   lsum += th[1];
   beta[2 * k] = th[0] / lsum;
   beta[2 * k + 1] = th[1] / lsum;
+}
+
+// captured graph: hand the next two descriptors of the ring to the graph that runs next, advance the cursor
+__device__ __forceinline__ void step_advance(const ammsb_step_advance& adv) {
+  if (!adv.ring) return;
+  const uint32_t c = *adv.cursor;
+  *adv.cur_out = adv.ring[c + 1];
+  *adv.nxt_out = adv.ring[c + 2];
+  *adv.cursor = c + 1;
+}
+
+__global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* beta, const float* grads,
+                                                           ammsb_seed* seeds, uint32_t K, float eps_t, float scale,
+                                                           float eta0, float eta1, uint32_t noise_on,
+                                                           const ammsb_step_desc* desc, const ammsb_step_advance adv) {
+  __shared__ ZigTables zig;
+  zig_load(&zig);
+  __syncthreads();
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (desc) {  // captured graph: this step's scalars
+    eps_t = desc->eps_t;
+    scale = desc->scale;
+    if (k == 0) step_advance(adv);
+  }
+  if (k >= K) return;
+  theta_step(k, grads[2 * k], grads[2 * k + 1], theta, beta, seeds, eps_t, scale, eta0, eta1, noise_on, &zig);
+}
+
+// sum_grads + update_theta in one launch (captured graph): block b reduces columns 8b .. 8b+7 of the partial rows
+// exactly as sum_partials8_kernel does (same row-lane assignment, same tree), stores them to grads_out
+// (BetaUpdater::GetGrads()), and its first four threads then run the theta step of components 4b .. 4b+3.
+__global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* partials, uint32_t P, uint32_t cols,
+                                                                float* grads_out, float* theta, float* beta,
+                                                                ammsb_seed* seeds, float eta0, float eta1,
+                                                                uint32_t noise_on, const ammsb_step_desc* desc,
+                                                                const ammsb_step_advance adv) {
+  __shared__ float4 red[128][2];
+  __shared__ ZigTables zig;
+  zig_load(&zig);
+  P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)
+  const uint32_t h = threadIdx.x & 1, r = threadIdx.x >> 1;
+  const uint32_t c = blockIdx.x * 8 + 4 * h;
+  float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (uint32_t p = r; p < P; p += 128) {
+    const float4 v = *reinterpret_cast<const float4*>(partials + (uint64_t)p * cols + c);
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  red[r][h] = s;
+  __syncthreads();
+  for (uint32_t half = 64; half > 0; half >>= 1) {
+    if (r < half) {
+      float4 x = red[r][h];
+      const float4 y = red[r + half][h];
+      x.x += y.x;
+      x.y += y.y;
+      x.z += y.z;
+      x.w += y.w;
+      red[r][h] = x;
+    }
+    __syncthreads();
+  }
+  if (r == 0) *reinterpret_cast<float4*>(grads_out + c) = red[0][h];
+  if (blockIdx.x == 0 && threadIdx.x == 0) step_advance(adv);
+  if (threadIdx.x < 4) {
+    const uint32_t k = blockIdx.x * 4 + threadIdx.x;  // columns 2k, 2k+1 = words (t & 1) * 2, +1 of red[0][t >> 1]
+    const float4 g = red[0][threadIdx.x >> 1];
+    const float g0 = (threadIdx.x & 1) ? g.z : g.x, g1 = (threadIdx.x & 1) ? g.w : g.y;
+    theta_step(k, g0, g1, theta, beta, seeds, desc->eps_t, desc->scale, eta0, eta1, noise_on, &zig);
+  }
 }
 
 __global__ void beta_from_theta_kernel(const float* theta, float* beta, uint32_t K) {
@@ -546,9 +633,10 @@ inline int pick_kpt(uint64_t K, uint32_t L) {
     default: return AMMSB_EINVAL;                                     \
   }
 
-extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
-                                const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
-                                uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream) {
+static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                             const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
+                             uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out,
+                             const ammsb_step_desc* desc, bool sum_rows, uint32_t* slots_out, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && pi && training_set && edges && grads_out, "null argument");
   AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
                   "bad pi descriptor");
@@ -580,9 +668,12 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
   a.edge_end = edge_end;
   a.K = K;
   a.epsilon = ctx->params.epsilon;
+  a.desc = desc;
   const uint32_t span = edge_end - edge_begin;
-  // enough slots to fill the chip (~8 waves per CU), never more than there are edges
-  uint32_t want = (uint32_t)ctx->num_cus * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
+  // enough slots to fill an MI355X (256 CUs, ~8 waves each), never more than there are edges.  A function of
+  // (span, wg) only -- not of the CU count visible to this process -- so that the summation order of the
+  // gradient, and with it theta and beta, is the same under every partition mode of the device.
+  uint32_t want = 256u * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
   if (const char* ov = getenv("AMMSB_BETA_SLOTS")) want = (uint32_t)atoi(ov);  // tuning override
   if (want < 64) want = 64;
   if (want > ctx->max_partials) want = ctx->max_partials;
@@ -611,10 +702,51 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
                            if (rc2) return rc2;
                          }));
   }
+  if (slots_out) *slots_out = a.P;
+  if (!sum_rows) {
+    AMMSB_LAUNCH_CHECK(ctx);
+    return AMMSB_OK;
+  }
   if ((2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0)
-    sum_partials8_kernel<<<2 * K / 8, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
+    sum_partials8_kernel<<<2 * K / 8, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out, desc);
   else
-    sum_partials_kernel<<<(2 * K + 15) / 16, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out);
+    sum_partials_kernel<<<(2 * K + 15) / 16, 256, 0, s>>>(a.partials, a.P, 2 * K, grads_out, desc);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                                const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
+                                uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream) {
+  return beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges, edge_begin, edge_end, wg, grads_out,
+                           nullptr, true, nullptr, stream);
+}
+
+int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                       const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg,
+                       float* grads_out, const ammsb_step_desc* desc, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && desc && n_edges_cap > 0, "null descriptor / empty capacity");
+  return beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges_cap, 0, n_edges_cap, wg, grads_out, desc,
+                           true, nullptr, stream);
+}
+
+// The gradient and the theta/beta step of one captured iteration: partial rows, then ONE kernel that sums them into
+// grads_out and steps theta (falls back to the separate sum and step kernels for shapes the fused one does not take).
+int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
+                      const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg, float* grads_out, ammsb_seed* seeds,
+                      uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && desc && adv && seeds && n_edges_cap > 0, "null argument / empty capacity");
+  const ammsb_params& p = ctx->params;
+  const uint32_t K = (uint32_t)p.K;
+  const bool fused = (2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0;
+  uint32_t slots = 0;
+  int rc = beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges_cap, 0, n_edges_cap, wg, grads_out, desc,
+                             !fused, &slots, stream);
+  if (rc != AMMSB_OK) return rc;
+  if (!fused) return ammsb_update_theta_d(ctx, theta, beta, grads_out, seeds, flags, desc, adv, stream);
+  sum_update_theta_kernel<<<2 * K / 8, 256, 0, as_stream(stream)>>>(ctx->grad_partials, slots, 2 * K, grads_out, theta, beta,
+                                                                      seeds, p.eta0, p.eta1,
+                                                                      (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc, *adv);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -631,9 +763,24 @@ extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, con
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K,
                                                                      ammsb_eps_t(&p, step_count), scale, p.eta0,
-                                                                     p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u);
+                                                                     p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u,
+                                                                     nullptr, none);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, ammsb_seed* seeds,
+                         uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds && desc, "null argument");
+  const ammsb_params& p = ctx->params;
+  const uint32_t K = (uint32_t)p.K;
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr};
+  update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K, 0.0f, 0.0f, p.eta0,
+                                                                     p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc,
+                                                                     adv ? *adv : none);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

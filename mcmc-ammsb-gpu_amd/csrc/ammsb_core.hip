@@ -6,6 +6,7 @@
 
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
+#include "ammsb_step.h"
 
 using namespace ammsb;
 
@@ -114,6 +115,36 @@ extern "C" int ammsb_rng_init(ammsb_ctx* ctx, ammsb_seed* seeds, uint64_t n, uin
   if (n == 0) return AMMSB_OK;
   const uint32_t grid = div_up(n, 256) < 4096 ? div_up(n, 256) : 4096;
   rng_init_kernel<<<grid, 256, 0, as_stream(stream)>>>(seeds, n, sx, sy);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+// Streams for NEW consumers (the device mini-batch sampler): the reference's {sx+i, sy+i} layout gives
+// neighbouring streams almost identical small states, and the first outputs of xorshift128+ from such states are
+// strongly correlated across streams (measured: 75k second draws mod 1M gave only 63.8k distinct values, where
+// independent draws give 72.5k).  Each word is passed through the SplitMix64 finaliser instead.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ void rng_init_mixed_kernel(ammsb_seed* seeds, uint64_t n, uint64_t sx, uint64_t sy) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x = splitmix64(sx + 2 * i), y = splitmix64(sy + 2 * i + 1);
+  if ((x | y) == 0) x = 1;  // the all-zero state is xorshift128+'s fixed point
+  seeds[i].x = x;
+  seeds[i].y = y;
+}
+
+extern "C" int ammsb_rng_init_mixed(ammsb_ctx* ctx, ammsb_seed* seeds, uint64_t n, uint64_t sx, uint64_t sy,
+                                    void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && seeds, "null argument");
+  if (n == 0) return AMMSB_OK;
+  const uint64_t grid = (n + 255) / 256;
+  AMMSB_CHECK_ARG(ctx, grid <= 0x7fffffffull, "too many streams");
+  rng_init_mixed_kernel<<<(uint32_t)grid, 256, 0, as_stream(stream)>>>(seeds, n, sx, sy);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -243,9 +274,22 @@ __device__ __forceinline__ void ns_generate(ammsb_seed& seed, uint32_t* out, uin
   } while (val == r);
 }
 
+// sample.cc:116-119: the reference's global size for n_nodes samples and work-group size wg
+__host__ __device__ __forceinline__ uint32_t ns_global_size(uint32_t n_nodes, uint32_t wg) {
+  uint32_t groups = n_nodes / wg + (n_nodes % wg ? 1 : 0);
+  const uint32_t maxg = AMMSB_MAX_GROUPS / wg;
+  if (groups > maxg) groups = maxg;
+  return groups * wg;
+}
+
 __global__ __launch_bounds__(64) void sample_neighbors_kernel(ammsb_seed* seeds, const uint32_t* nodes,
                                                                uint32_t n_nodes, uint32_t N, uint32_t n,
-                                                               uint32_t gsize, uint32_t* table, uint32_t* packed) {
+                                                               uint32_t gsize, uint32_t* table, uint32_t* packed,
+                                                               const ammsb_step_desc* desc, uint32_t wg) {
+  if (desc) {  // captured graph: the grid covers the largest mini-batch
+    n_nodes = desc->n_nodes;
+    gsize = ns_global_size(n_nodes, wg);
+  }
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= gsize || gid >= n_nodes) return;
   const uint32_t capacity = 2 * n;
@@ -272,7 +316,13 @@ __global__ __launch_bounds__(64) void sample_neighbors_kernel(ammsb_seed* seeds,
 // NeighborSampler::GetHash() exposes it).  Results are identical by construction.
 __global__ __launch_bounds__(64) void sample_neighbors_lds_kernel(ammsb_seed* seeds, const uint32_t* nodes,
                                                                    uint32_t n_nodes, uint32_t N, uint32_t n,
-                                                                   uint32_t gsize, uint32_t* table, uint32_t* packed) {
+                                                                   uint32_t gsize, uint32_t* table, uint32_t* packed,
+                                                                   const ammsb_step_desc* desc, uint32_t wg) {
+  if (desc) {  // captured graph: the grid covers the largest mini-batch
+    n_nodes = desc->n_nodes;
+    gsize = ns_global_size(n_nodes, wg);
+    if (blockIdx.x * 64 >= gsize || blockIdx.x * 64 >= n_nodes) return;  // block-uniform: no lane owns a node
+  }
   // [capacity][65]: slot j of lane l at j * 65 + l.  A lane probing its own table touches one bank whatever the
   // slot; the transposed read-back below (consecutive lanes = consecutive slots of one node) strides by 65 and
   // is conflict-free too (a stride of 64 would put all 64 lanes on one bank).
@@ -361,26 +411,35 @@ __global__ __launch_bounds__(64) void sample_neighbors_lds_kernel(ammsb_seed* se
   if (owner) seeds[gid] = seed;
 }
 
-extern "C" int ammsb_sample_neighbors(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes,
-                                      uint32_t wg, uint32_t* table, uint32_t* packed, void* stream) {
+static int sample_neighbors_common(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes,
+                                   uint32_t wg, uint32_t* table, uint32_t* packed, const ammsb_step_desc* desc,
+                                   void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && seeds && nodes && table && packed, "null argument");
   AMMSB_CHECK_ARG(ctx, wg >= 1 && wg <= 1024, "sampler wg out of range");
   if (n_nodes == 0) return AMMSB_OK;
   const uint32_t n = ctx->params.num_node_sample;
   AMMSB_CHECK_ARG(ctx, ctx->params.N > (uint64_t)n + 1, "N must exceed num_node_sample + 1");
-  uint32_t groups = n_nodes / wg + (n_nodes % wg ? 1 : 0);  // sample.cc:116-119
-  const uint32_t maxg = AMMSB_MAX_GROUPS / wg;
-  if (groups > maxg) groups = maxg;
-  const uint32_t gsize = groups * wg;
+  const uint32_t gsize = ns_global_size(n_nodes, wg);  // sample.cc:116-119
   const size_t lds_bytes = (size_t)2 * n * 65 * sizeof(uint32_t);
   if (lds_bytes <= 64 * 1024)
     sample_neighbors_lds_kernel<<<div_up(gsize, 64), 64, lds_bytes, as_stream(stream)>>>(
-        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed);
+        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed, desc, wg);
   else
     sample_neighbors_kernel<<<div_up(gsize, 64), 64, 0, as_stream(stream)>>>(
-        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed);
+        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed, desc, wg);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
+}
+
+extern "C" int ammsb_sample_neighbors(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes,
+                                      uint32_t wg, uint32_t* table, uint32_t* packed, void* stream) {
+  return sample_neighbors_common(ctx, seeds, nodes, n_nodes, wg, table, packed, nullptr, stream);
+}
+
+int ammsb_sample_neighbors_d(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes_cap, uint32_t wg,
+                             uint32_t* table, uint32_t* packed, const ammsb_step_desc* desc, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && desc, "null descriptor");
+  return sample_neighbors_common(ctx, seeds, nodes, n_nodes_cap, wg, table, packed, desc, stream);
 }
 
 // ----------------------------------------------------------------------------- wg primitives

@@ -20,6 +20,7 @@
 
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
+#include "ammsb_step.h"
 
 #include <type_traits>
 
@@ -40,7 +41,33 @@ struct PhiArgs {
   uint32_t K, n;
   float eps_t, alpha, epsilon, Nn;
   uint32_t noise_on;
+  const ammsb_step_desc* desc;  // non-null (captured graph): n_nodes and eps_t come from here, all groups run
+  unsigned long long* stamps;   // optional (with desc): block 0 notes the device time at which it starts
 };
+
+// Device wall-clock stamps without extra launches: block 0 of update_phi notes when it starts (slot 0), block 0 of
+// update_pi -- the next kernel on the stream -- when IT starts (slot 1).  The difference is update_phi's duration
+// plus one kernel boundary: a slight over-estimate, never an under-estimate.
+__device__ __forceinline__ void note_stamp(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
+  if (stamps && desc && blockIdx.x == 0 && threadIdx.x == 0)
+    stamps[2 * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
+}
+
+// the per-iteration scalars, from the descriptor when there is one (block-uniform scalar loads)
+struct PhiStep {
+  uint32_t n_nodes, G, group_end;
+  float eps_t;
+};
+__device__ __forceinline__ PhiStep phi_step(const PhiArgs& a) {
+  PhiStep st = {a.n_nodes, a.G, a.group_end, a.eps_t};
+  if (a.desc) {
+    st.n_nodes = a.desc->n_nodes;
+    st.G = st.n_nodes < AMMSB_MAX_GROUPS ? st.n_nodes : AMMSB_MAX_GROUPS;
+    st.group_end = st.G;
+    st.eps_t = a.desc->eps_t;
+  }
+  return st;
+}
 
 // FULL: K == L * KPT, so no column guard is needed anywhere.  Loads are always unconditional (row
 // and column indices are clamped instead of predicated): a predicated load turns into a branch plus a
@@ -55,8 +82,10 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
   const int l = Grp::lane();
   const int slot = Grp::slot();
   uint32_t* s_nb = s_nb_all + slot * a.n;
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, 0);
   const uint32_t g = a.group_begin + blockIdx.x * Grp::PER_BLOCK + slot;
-  const bool live = g < a.group_end;
+  const bool live = g < st.group_end;
   const uint32_t K = a.K, n = a.n;
   const float EPS = a.epsilon;
 
@@ -83,11 +112,11 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
   ammsb_seed rs = {0, 0};
   if (live && a.noise_on) rs = a.seeds[(uint64_t)g * L + l];  // rand->base_[GET_GLOBAL_ID()], phi.cc:291
 
-  const uint32_t trips = (a.n_nodes + a.G - 1) / a.G;  // uniform over the block
+  const uint32_t trips = (st.n_nodes + st.G - 1) / st.G;  // uniform over the block
   int phase = 0;
   for (uint32_t t = 0; t < trips; ++t) {
-    const uint64_t i_raw = (uint64_t)g + (uint64_t)t * a.G;  // node index handled by this group
-    const bool on = live && i_raw < a.n_nodes;
+    const uint64_t i_raw = (uint64_t)g + (uint64_t)t * st.G;  // node index handled by this group
+    const bool on = live && i_raw < st.n_nodes;
     if constexpr (Grp::PER_BLOCK == 1) {
       if (!on) continue;  // block-uniform: every thread skips the barriers below together
     }
@@ -206,7 +235,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
     // ---- SGLD step, phi.cc:265-274; lane l draws for k = l, l+L, ... in ascending order
     if (on) {
       float* out = a.phi_vec + i * K;
-      const float half = a.eps_t / 2;
+      const float half = st.eps_t / 2;
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {
         if (has(j)) {
@@ -217,7 +246,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
           in = in + ng;
           const float drift = half * in;
           const float aa = phi_k + drift;
-          const float ep = a.eps_t * phi_k;
+          const float ep = st.eps_t * phi_k;
           const float sq = sqrtf(ep);
           const float bb = sq * noise;
           const float v = fabsf(aa + bb);
@@ -242,11 +271,22 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
 // and re-reads it for the gradient pass.  ~100 VGPRs -> 4 waves per SIMD, 16 rows in flight per CU.
 // Arithmetic, operation order and RNG consumption are those of the register kernel, bit for bit.
 
+// minimum waves per SIMD the register allocator must allow for the short-row kernels (K = 256 / 512): their
+// per-row work is latency-bound, so they want more resident waves than the 4 KiB-row kernel (A/B: tools/gpu_exp.sh)
+#ifndef AMMSB_PHI_WPE4
+#define AMMSB_PHI_WPE4 3
+#endif
+#ifndef AMMSB_PHI_WPE8
+#define AMMSB_PHI_WPE8 3
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-template <int KPT, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
+// D = ring depth (power of two): rows q+1 .. q+D-1 are in flight while row q is reduced.  Two slots are right for
+// 4 KiB rows (K = 1024: LDS, not latency, limits the waves per CU); short rows (K = 256: one 1 KiB piece per
+// row) need more rows in flight per wave to keep enough bytes on their way to each CU.
+template <int KPT, int W, int D = 2>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 4 ? AMMSB_PHI_WPE4 : KPT <= 8 ? AMMSB_PHI_WPE8 : KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
   // L = 64 W lanes per node: wave wv owns columns 64 wv + ln + L j, i.e. KPT chunks of 64 consecutive floats per
   // row.  Each wave runs the single-wave pipeline on its own slice (own ring, own waits); the only cross-wave
   // step is the WG_SUM of a neighbour's probs: one LDS exchange and one barrier per row.
@@ -254,17 +294,20 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
   constexpr int KW = 64 * KPT;     // floats of a row that one wave handles
   constexpr int K = L * KPT;
   constexpr int PIECES = KPT / 4;  // 1 KiB LDS-DMA pieces per wave and row (4 chunks of 256 B each)
-  extern __shared__ __align__(16) char smem[];  // per wave: [2][KW] ring, [KW] normals; then [n] u32 (id | link bit)
+  static_assert(D >= 2 && (D & (D - 1)) == 0 && (D - 1) * PIECES <= 63, "ring depth");
+  extern __shared__ __align__(16) char smem[];  // per wave: [D][KW] ring, [KW] normals; then [n] u32 (id | link bit)
   __shared__ ZigTables zig;
   __shared__ float xsum[W > 1 ? 2 * L : 1];  // double-buffered lane partials of the cross-wave sum
   const int tid = threadIdx.x, wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
-  char* wave_smem = smem + wv * (3 * KW * sizeof(float));
+  char* wave_smem = smem + wv * ((D + 1) * KW * sizeof(float));
   float* ring = reinterpret_cast<float*>(wave_smem);
-  float* s_noise = ring + 2 * KW;
-  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + W * 3 * KW * sizeof(float));
+  float* s_noise = ring + D * KW;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + W * (D + 1) * KW * sizeof(float));
 
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, 0);
   const uint32_t g = a.group_begin + blockIdx.x;
-  if (g >= a.group_end) return;  // block-uniform
+  if (g >= st.group_end) return;  // block-uniform
   const uint32_t n = a.n;
   const float EPS = a.epsilon;
   if (a.noise_on) zig_load(&zig);
@@ -317,7 +360,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
     }
   };
 
-  for (uint64_t i = g; i < a.n_nodes; i += a.G) {
+  for (uint64_t i = g; i < st.n_nodes; i += st.G) {
     const uint32_t node = a.nodes[i];
     __syncthreads();  // orders the LDS traffic of consecutive nodes
     for (uint32_t q = tid; q < n; q += L) {
@@ -335,7 +378,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
 #pragma unroll
     for (int p = 0; p < HP; ++p)
       pi_a[p] = f32x2{__builtin_nontemporal_load(row_a + tid + 2 * L * p), __builtin_nontemporal_load(row_a + tid + 2 * L * p + L)};
-    request(0, 0);  // the first row's flight overlaps the per-node set-up below
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)(D - 1); ++r)
+      if (r < n) request(r, r);  // the first rows' flight overlaps the per-node set-up below
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
       grads[p] = f32x2{0.0f, 0.0f};
@@ -344,24 +389,43 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
       node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
       // sqrt(eps_t * phi_k) of the SGLD step does not depend on the gradient: computed here, under the first
       // row's latency, and parked in the noise slot, where the loop multiplies the normal in
-      const f32x2 ep = den * a.eps_t;
+      const f32x2 ep = den * st.eps_t;
       s_noise[ln + 128 * p] = sqrtf(ep.x);
       s_noise[ln + 128 * p + 64] = sqrtf(ep.y);
     }
 
     for (uint32_t q = 0; q < n; ++q) {
-      const uint32_t slot = q & 1;
+      const uint32_t slot = q & (D - 1);
       float* row = ring + slot * KW;
-      // every LDS read of the other slot (row q-1) has been consumed; refill it with row q+1
+      // every LDS read of the slot of row q-1 has been consumed; refill it with row q+D-1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (q + 1 < n) {
-        request(q + 1, slot ^ 1);
+      if (q + (D - 1) < n) {
+        request(q + (D - 1), (q + (D - 1)) & (D - 1));
         // one of the lane's KPT normals per iteration, drawn while row q is still on its way (stream order is
         // the ascending column order of the SGLD step below)
         if (a.noise_on && q < (uint32_t)KPT) s_noise[ln + 64 * q] = s_noise[ln + 64 * q] * rng_normal(rs, &zig);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");  // row q landed, row q+1 in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PIECES) : "memory");  // row q landed, D-1 rows in flight
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (D > 2) {  // (D == 2 keeps the round-1 instruction stream: the last row draws no normal)
+          if (a.noise_on && q < (uint32_t)KPT) s_noise[ln + 64 * q] = s_noise[ln + 64 * q] * rng_normal(rs, &zig);
+        }
+        // the tail: rows q+1 .. n-1 (fewer than D-1) are still in flight
+        const uint32_t rem = n - 1 - q;
+        if constexpr (D == 2) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (D == 4) {
+          if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+          else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PIECES) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          if (rem >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PIECES) : "memory");
+          else if (rem == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PIECES) : "memory");
+          else if (rem == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PIECES) : "memory");
+          else if (rem == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES) : "memory");
+          else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+          else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PIECES) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
       }
       bool y = (s_nb[q] >> 31) != 0;
       y = __builtin_amdgcn_readfirstlane((int)y) != 0;
@@ -418,14 +482,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
     // normals the loop did not get to (n - 1 < KPT): one rolled loop, a single copy of the ziggurat code
     if (a.noise_on) {
 #pragma unroll 1
-      for (uint32_t j = n > 0 ? n - 1 : 0; j < (uint32_t)KPT; ++j)
+      for (uint32_t j = D > 2 ? n : (n > 0 ? n - 1 : 0); j < (uint32_t)KPT; ++j)
         s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // SGLD step, phi.cc:265-274
     float* out = a.phi_vec + i * K;
-    const float half = a.eps_t / 2;
+    const float half = st.eps_t / 2;
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
       const f32x2 bb = f32x2{s_noise[ln + 128 * p], s_noise[ln + 128 * p + 64]};  // sqrt(eps_t * phi_k) * noise
@@ -444,10 +508,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 1
   if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
 }
 
-template <int KPT, int W>
+template <int KPT, int W, int D = 2>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
-  const size_t lds = (size_t)W * 3 * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
-  update_phi_lds_kernel<KPT, W><<<n_groups, 64 * W, lds, s>>>(a);
+  const size_t lds = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  update_phi_lds_kernel<KPT, W, D><<<n_groups, 64 * W, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -456,9 +520,13 @@ int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStrea
 template <int L, int KPT>
 __global__ __launch_bounds__(Group<L>::BLOCK) void update_pi_kernel(ammsb_rpm pi, float* phi_sum,
                                                                      const float* phi_vec, const uint32_t* nodes,
-                                                                     uint32_t n_nodes, uint32_t K) {
+                                                                     uint32_t n_nodes, uint32_t K,
+                                                                     const ammsb_step_desc* desc,
+                                                                     unsigned long long* stamps) {
   using Grp = Group<L>;
   __shared__ float aux[Grp::AUX];
+  if (desc) n_nodes = desc->n_nodes;  // captured graph: the grid covers the largest mini-batch
+  note_stamp(stamps, desc, 1);
   const int l = Grp::lane();
   const uint64_t i = (uint64_t)blockIdx.x * Grp::PER_BLOCK + Grp::slot();
   const bool on = i < n_nodes;
@@ -501,10 +569,10 @@ int launch_phi(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t 
 
 template <int L, int KPT>
 int launch_pi(ammsb_ctx* ctx, const ammsb_rpm& pi, float* phi_sum, const float* phi_vec, const uint32_t* nodes,
-              uint32_t n_nodes, uint32_t K, hipStream_t s) {
+              uint32_t n_nodes, uint32_t K, const ammsb_step_desc* desc, unsigned long long* stamps, hipStream_t s) {
   using Grp = Group<L>;
   const uint32_t blocks = (n_nodes + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
-  update_pi_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(pi, phi_sum, phi_vec, nodes, n_nodes, K);
+  update_pi_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(pi, phi_sum, phi_vec, nodes, n_nodes, K, desc, stamps);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -542,10 +610,11 @@ inline int pick_kpt(uint64_t K, uint32_t L) {
     default: return AMMSB_EINVAL;                                     \
   }
 
-extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
-                                const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
-                                uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
-                                uint32_t group_begin, uint32_t group_end, float* phi_vec, void* stream) {
+static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
+                             const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
+                             uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
+                             uint32_t group_begin, uint32_t group_end, float* phi_vec, const ammsb_step_desc* desc,
+                             unsigned long long* stamps, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && beta && pi && phi_sum && training_set && nodes && neighbors && seeds && phi_vec,
                   "null argument");
   AMMSB_CHECK_ARG(ctx, n_nodes > 0, "mini-batch nodes size = 0");  // phi.cc:732
@@ -578,7 +647,9 @@ extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_r
   a.group_end = group_end < a.G ? group_end : a.G;
   a.K = (uint32_t)p.K;
   a.n = p.num_node_sample;
-  a.eps_t = ammsb_eps_t(&p, step_count);
+  a.eps_t = desc ? 0.0f : ammsb_eps_t(&p, step_count);
+  a.desc = desc;
+  a.stamps = stamps;
   a.alpha = p.alpha;
   a.epsilon = p.epsilon;
   a.Nn = (1.0f * (float)p.N) / (float)p.num_node_sample;  // phi.cc:265
@@ -593,10 +664,19 @@ extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_r
   // LDS-streamed kernels: K == wg * kpt exactly.  One wave per node up to K = 2048 (wg 64); for longer rows the
   // node is spread over wg / 64 waves with 16 columns per lane (K = 4096: wg 256, K = 8192: wg 512, ...).
   if (!force_reg && p.K == (uint64_t)wg * kpt && pi->num_cols % 4 == 0 && a.n * sizeof(uint32_t) <= 8192) {
+    static const int ring = [] {  // AMMSB_PHI_RING=2|4|8: ring depth of the short-row kernels (A/B runs)
+      const char* f = getenv("AMMSB_PHI_RING");
+      return f ? atoi(f) : 0;
+    }();
     if (wg == 64) {
       switch (kpt) {
-        case 4: return launch_phi_lds<4, 1>(ctx, a, n_groups, s);
-        case 8: return launch_phi_lds<8, 1>(ctx, a, n_groups, s);
+        case 4:
+          if (ring == 2) return launch_phi_lds<4, 1, 2>(ctx, a, n_groups, s);
+          if (ring == 4) return launch_phi_lds<4, 1, 4>(ctx, a, n_groups, s);
+          return launch_phi_lds<4, 1, 8>(ctx, a, n_groups, s);
+        case 8:
+          if (ring == 2) return launch_phi_lds<8, 1, 2>(ctx, a, n_groups, s);
+          return launch_phi_lds<8, 1, 4>(ctx, a, n_groups, s);
         case 16: return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
         case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);
       }
@@ -614,8 +694,26 @@ extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_r
   return AMMSB_OK;
 }
 
-extern "C" int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
-                               const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, void* stream) {
+extern "C" int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
+                                const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
+                                uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
+                                uint32_t group_begin, uint32_t group_end, float* phi_vec, void* stream) {
+  return update_phi_common(ctx, beta, pi, phi_sum, training_set, nodes, neighbors, n_nodes, step_count, seeds, wg, flags,
+                           group_begin, group_end, phi_vec, nullptr, nullptr, stream);
+}
+
+int ammsb_update_phi_d(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
+                       const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
+                       uint32_t n_nodes_cap, ammsb_seed* seeds, uint32_t wg, uint32_t flags, float* phi_vec,
+                       const ammsb_step_desc* desc, unsigned long long* stamps, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && desc, "null descriptor");
+  return update_phi_common(ctx, beta, pi, phi_sum, training_set, nodes, neighbors, n_nodes_cap, 0, seeds, wg, flags, 0,
+                           0xFFFFFFFFu, phi_vec, desc, stamps, stream);
+}
+
+static int update_pi_common(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
+                            const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, const ammsb_step_desc* desc,
+                            unsigned long long* stamps, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && pi && phi_sum && phi_vec && nodes, "null argument");
   AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
                   "bad pi descriptor");
@@ -627,6 +725,18 @@ extern "C" int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_s
   const uint32_t K = (uint32_t)ctx->params.K;
   hipStream_t s = as_stream(stream);
   AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, return (launch_pi<L_, KPT_>(ctx, *pi, phi_sum, phi_vec, nodes,
-                                                                                n_nodes, K, s))));
+                                                                                n_nodes, K, desc, stamps, s))));
   return AMMSB_OK;
+}
+
+extern "C" int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
+                               const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, void* stream) {
+  return update_pi_common(ctx, pi, phi_sum, phi_vec, nodes, n_nodes, wg, nullptr, nullptr, stream);
+}
+
+int ammsb_update_pi_d(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec, const uint32_t* nodes,
+                      uint32_t n_nodes_cap, uint32_t wg, const ammsb_step_desc* desc, unsigned long long* stamps,
+                      void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && desc, "null descriptor");
+  return update_pi_common(ctx, pi, phi_sum, phi_vec, nodes, n_nodes_cap, wg, desc, stamps, stream);
 }

@@ -1,0 +1,59 @@
+// Device-resident step descriptor + the descriptor-taking forms of the per-iteration enqueue functions.
+//
+// A captured hipGraph cannot take the per-iteration scalars (mini-batch sizes, eps_t, the sampler's vertex u)
+// by value: kernel parameters are frozen at capture.  Every hot-path kernel therefore accepts an optional
+// pointer to one of these; when it is non-null the kernel reads the sizes / step size from it (one scalar load
+// at block start) and the launch grid is sized for the largest mini-batch of that kind, surplus blocks leaving
+// at once.  With a null pointer the by-value arguments are used: the eager C-ABI path of include/ammsb.h.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/ammsb.h"
+
+#define AMMSB_STAMP_CAP 8192u  // steps whose update_phi time stamps are kept (ring indexed by step number)
+
+struct ammsb_step_desc {
+  uint32_t n_nodes;  // mini-batch nodes (phi / pi / neighbour sampler)
+  uint32_t n_edges;  // mini-batch edges (beta gradient)
+  float eps_t;       // get_eps_t(step_count), learner.cc:41-43, evaluated on the host by ammsb_eps_t()
+  float scale;       // the sampler's weight (sample.cc:268,292)
+  uint32_t u;        // shared end point of the mini-batch (device sampler)
+  uint32_t link;     // 1 = link batch (all training edges of u), 0 = non-link batch
+  uint32_t n_cand;   // candidate draws of a non-link batch (multiple of 256, <= the sampler's capacity)
+  uint32_t step;     // step_count (1-based), index of the optional timestamps
+};
+
+// what update_theta does last in a captured step: hand the next two descriptors of the ring to the graph
+// that runs next (which has the other buffer parity), and advance the cursor
+struct ammsb_step_advance {
+  const ammsb_step_desc* ring;  // device ring of upcoming descriptors
+  uint32_t* cursor;             // index of the CURRENT step's descriptor in ring
+  ammsb_step_desc* cur_out;     // <- ring[cursor + 1]
+  ammsb_step_desc* nxt_out;     // <- ring[cursor + 2]
+};
+
+// ---- descriptor forms (same checks and dispatch as the extern "C" functions; `cap` sizes the grid)
+int ammsb_update_phi_d(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
+                       const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
+                       uint32_t n_nodes_cap, ammsb_seed* seeds, uint32_t wg, uint32_t flags, float* phi_vec,
+                       const ammsb_step_desc* desc, unsigned long long* stamps, void* stream);
+int ammsb_update_pi_d(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec, const uint32_t* nodes,
+                      uint32_t n_nodes_cap, uint32_t wg, const ammsb_step_desc* desc, unsigned long long* stamps,
+                      void* stream);
+int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                       const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg,
+                       float* grads_out, const ammsb_step_desc* desc, void* stream);
+int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, ammsb_seed* seeds,
+                         uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream);
+int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
+                      const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg, float* grads_out, ammsb_seed* seeds,
+                      uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream);
+int ammsb_sample_neighbors_d(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes_cap, uint32_t wg,
+                             uint32_t* table, uint32_t* packed, const ammsb_step_desc* desc, void* stream);
+int ammsb_minibatch_link_d(ammsb_ctx* ctx, const uint64_t* csr_offsets, const uint32_t* csr_targets, uint32_t n_cap,
+                           uint64_t* edges_out, uint32_t* nodes_out, const ammsb_step_desc* desc, void* stream);
+int ammsb_minibatch_nonlink_d(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_candidates_cap, uint32_t m,
+                              const ammsb_set* training_set, const ammsb_set* heldout_set, void* workspace,
+                              uint64_t* edges_out, uint32_t* nodes_out, uint32_t* count_out,
+                              const ammsb_step_desc* desc, void* stream);

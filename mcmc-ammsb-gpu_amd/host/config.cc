@@ -43,6 +43,7 @@ Config::Config() {  // config.h:69-101
   sum_grads_vector_width = 1;
   device_sampling = false;
   async_launch = false;
+  graph_launch = false;
   device_sampling_seed = {1234, 5678};
   device_sampling_host_seed = 20260101;
   sample_seed[0] = 1804289383u;

@@ -7,12 +7,16 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <random>
 #include <sstream>
 #include <stdexcept>
+#include <string>
+#include <tuple>
 
 using namespace std::chrono;
 
@@ -61,11 +65,36 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
     for (uint64_t u = 0; u < cfg_.N; ++u) degree_[u] = static_cast<uint32_t>(off[u + 1] - off[u]);
     csr_offsets_.reset(new clcuda::Buffer<uint64_t>(queue_.GetContext(), queue_, off.begin(), off.end()));
     csr_targets_.reset(new clcuda::Buffer<Vertex>(queue_.GetContext(), queue_, tgt.begin(), tgt.end()));
-    candidates_ = ammsb_minibatch_candidates(cfg_.N, static_cast<uint32_t>(cfg_.mini_batch_size));
-    if (candidates_ == 0) throw std::runtime_error("device sampling needs N >= 2 * mini_batch");
+    // invalid non-link partners of u: u itself and its neighbours in the training and held-out graphs
+    // (sample.cc:283-285); the candidate draws of a mini-batch follow its vertex, the capacity the largest
+    excluded_.assign(cfg_.N, 1);
+    uint32_t max_excluded = 1;
+    for (uint64_t u = 0; u < cfg_.N; ++u) excluded_[u] += degree_[u];
+    if (cfg_.heldout)
+      for (Edge e : cfg_.heldout_edges)
+        if (cfg_.heldout->Has(e)) {
+          Vertex a, b;
+          std::tie(a, b) = Vertices(e);
+          ++excluded_[a];
+          ++excluded_[b];
+        }
+    for (uint64_t u = 0; u < cfg_.N; ++u) max_excluded = std::max(max_excluded, excluded_[u]);
+    candidates_ = CandidatesForExcluded(max_excluded);
+    if (candidates_ == 0)
+      throw std::runtime_error("device sampling needs N >= 2 * mini_batch with room for the largest degree");
     mb_rand_.reset(new random::OpenClRandom(queue_, candidates_, cfg_.device_sampling_seed));
+    // scrambled states: the reference's {s+i, s'+i} layout makes the streams' first draws collide far too often
+    ThrowIfError(ctx_.get(),
+                 ammsb_rng_init_mixed(ctx_.get(), mb_rand_->Get(), candidates_, cfg_.device_sampling_seed[0],
+                                      cfg_.device_sampling_seed[1], queue_.stream()),
+                 "ammsb_rng_init_mixed");
+    queue_.Finish();
     mb_workspace_.reset(new clcuda::Buffer<uint8_t>(queue_.GetContext(), ammsb_minibatch_workspace_bytes(candidates_)));
-    mb_count_.reset(new clcuda::Buffer<uint32_t>(queue_.GetContext(), 1));
+    // 0xFF once: every call leaves the de-duplication table empty again (include/ammsb.h)
+    clcuda::Check(hipMemset(mb_workspace_->data(), 0xFF, ammsb_minibatch_workspace_bytes(candidates_)), "hipMemset");
+    mb_count_.reset(new clcuda::Buffer<uint32_t>(queue_.GetContext(), 2));  // [0] last count, [1] sticky shortfalls
+    const uint32_t zero2[2] = {0, 0};
+    mb_count_->Write(queue_, 2, zero2);
     host_rng_.seed(cfg_.device_sampling_host_seed);
   }
   if (cfg_.async_launch) {
@@ -86,11 +115,76 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
   auto gamma = std::bind(gamma_distribution, mt19937);
   random::RandomAndNormalize(&queue_, gamma, &theta_, &beta_, 2);
   random::RandomGammaAndNormalize(&queue_, cfg_.eta0, cfg_.eta1, pi_.get(), &phi_);  // learner.cc:154-155
+  if (cfg_.graph_launch) {
+    if (!cfg_.async_launch || !cfg_.device_sampling)
+      throw std::runtime_error("graph_launch needs async_launch and device_sampling");
+    ammsb_loop_config lc;
+    std::memset(&lc, 0, sizeof lc);
+    lc.theta = theta_.data();
+    lc.beta = beta_.data();
+    lc.pi = &pi_->Get();
+    lc.phi_sum = phi_.data();
+    lc.training_set = &trainingSet_->Get();
+    lc.heldout_set = heldoutSet_ ? &heldoutSet_->Get() : nullptr;
+    lc.phi_seeds = phiUpdater_.Rand().Get();
+    lc.phi_vec = phiUpdater_.GetPhiVec().data();
+    lc.phi_wg = phiUpdater_.Local();
+    lc.phi_flags = phiUpdater_.Flags();
+    lc.beta_seeds = betaUpdater_.Rand().Get();
+    lc.grads = betaUpdater_.GetGrads().data();
+    lc.beta_wg = betaUpdater_.Local();
+    lc.beta_flags = 0;
+    for (int i = 0; i < 2; ++i) {
+      lc.edges[i] = samples_[i]->dev_edges.data();
+      lc.nodes[i] = samples_[i]->dev_nodes.data();
+      lc.neighbors[i] = samples_[i]->neighbor_sampler.GetData().data();
+      lc.nbr_table[i] = samples_[i]->neighbor_sampler.GetHash().data();
+      lc.nbr_seeds[i] = samples_[i]->neighbor_sampler.Rand().Get();
+    }
+    lc.nbr_wg = samples_[0]->neighbor_sampler.Local();
+    lc.csr_offsets = csr_offsets_->data();
+    lc.csr_targets = csr_targets_->data();
+    lc.mb_seeds = mb_rand_->Get();
+    lc.mb_candidates = candidates_;
+    lc.mb_workspace = mb_workspace_->data();
+    lc.mb_count = mb_count_->data();
+    lc.mini_batch = static_cast<uint32_t>(cfg_.mini_batch_size);
+    lc.max_fan_out = static_cast<uint32_t>(cfg_.trainingGraph->MaxFanOut());
+    lc.flags = 0;
+    queue_.Finish();
+    ThrowIfError(ctx_.get(), ammsb_loop_create(ctx_.get(), &lc, &loop_), "ammsb_loop_create");
+  }
+}
+
+uint32_t Learner::CandidatesForExcluded(uint32_t excluded) {
+  const uint32_t key = (excluded + 255u) / 256u * 256u;  // few distinct values
+  auto it = cand_cache_.find(key);
+  if (it != cand_cache_.end()) return it->second;
+  const uint32_t c = ammsb_minibatch_candidates_for(cfg_.N, static_cast<uint32_t>(cfg_.mini_batch_size), key);
+  cand_cache_[key] = c;
+  return c;
+}
+
+uint32_t Learner::CandidatesFor(uint64_t u) { return CandidatesForExcluded(excluded_[u]); }
+
+// A non-link mini-batch that found fewer than m distinct partners repeats entries to stay memory-safe; it is not a
+// valid sample.  The device counts them (sticky); this reads the counter at a synchronisation point.
+void Learner::CheckDeviceSampler() {
+  if (!cfg_.device_sampling) return;
+  uint32_t cnt[2] = {0, 0};
+  mb_count_->Read(queue_, 2, cnt);
+  if (cnt[1] != 0) {
+    const uint32_t zero2[2] = {0, 0};
+    mb_count_->Write(queue_, 2, zero2);
+    throw std::runtime_error("device mini-batch sampler: " + std::to_string(cnt[1]) +
+                             " mini-batch(es) found fewer than mini_batch_size distinct non-links");
+  }
 }
 
 Learner::~Learner() {
   for (auto& f : futures_)
     if (f.valid()) f.wait();
+  if (loop_) ammsb_loop_destroy(loop_);
   if (cfg_.async_launch) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) {
@@ -104,55 +198,63 @@ Learner::~Learner() {
 // Device-side replacement for sampleNode + ExtractNodesFromMiniBatch (sample.cc:249-303, learner.cc:162-173):
 // the coin flip and the choice of u stay on the host, so the sizes are known without a read-back; the m
 // distinct non-links / the edges of u are produced on the device straight into the sample's buffers.
-Float Learner::DoSampleDevice(Sample* sample) {
+ammsb_mb_choice Learner::ChooseDevice() {
   bool link = cfg_.strategy == NodeLink;
   if (cfg_.strategy == Node) link = (host_rng_() & 1u) != 0;  // rand_r(seed) % 2, sample.cc:297
   const uint64_t N = cfg_.N;
-  void* stream = sample->queue.stream();
-  // async: the candidate streams, workspace and counter are shared by the two samples' streams
-  auto sampler_begin = [&] {
-    if (cfg_.async_launch && sampler_valid_)
-      clcuda::Check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_sampler_), 0),
-                    "hipStreamWaitEvent");
-  };
-  auto sampler_end = [&] {
-    if (cfg_.async_launch) {
-      clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_sampler_), static_cast<hipStream_t>(stream)), "hipEventRecord");
-      sampler_valid_ = true;
-    }
-  };
-  sampler_begin();
+  ammsb_mb_choice ch = {0, 0, 0, 0};
   if (link) {
     uint64_t u;
     do {  // sampleNodeLink retries until the vertex has an edge, sample.cc:254-263
       u = host_rng_() % N;
     } while (degree_[u] == 0);
-    const uint32_t n = degree_[u];
+    ch.link = 1;
+    ch.u = static_cast<uint32_t>(u);
+    ch.n = degree_[u];
+    return ch;
+  }
+  ch.u = static_cast<uint32_t>(host_rng_() % N);
+  ch.n_candidates = CandidatesFor(ch.u);
+  return ch;
+}
+
+Float Learner::EnqueueDevice(Sample* sample, const ammsb_mb_choice& ch) {
+  const uint64_t N = cfg_.N;
+  void* stream = sample->queue.stream();
+  // async: the candidate streams, workspace and counter are shared by the two samples' streams
+  if (cfg_.async_launch && sampler_valid_)
+    clcuda::Check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_sampler_), 0),
+                  "hipStreamWaitEvent");
+  const uint32_t m = static_cast<uint32_t>(cfg_.mini_batch_size);
+  if (ch.link)
     ThrowIfError(ctx_.get(),
-                 ammsb_minibatch_link(ctx_.get(), csr_offsets_->data(), csr_targets_->data(), static_cast<uint32_t>(u), n,
+                 ammsb_minibatch_link(ctx_.get(), csr_offsets_->data(), csr_targets_->data(), ch.u, ch.n,
                                       sample->dev_edges.data(), sample->dev_nodes.data(), stream),
                  "ammsb_minibatch_link");
-    sampler_end();
-    if (!cfg_.async_launch) sample->queue.Finish();  // the neighbour sampler runs on its own queue
-    sample->num_edges = n;
-    sample->num_nodes = n + 1;
-    sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
-    return static_cast<Float>(N);  // sample.cc:268
+  else
+    ThrowIfError(ctx_.get(),
+                 ammsb_minibatch_nonlink(ctx_.get(), mb_rand_->Get(), ch.n_candidates, candidates_, ch.u, m,
+                                         &trainingSet_->Get(), heldoutSet_ ? &heldoutSet_->Get() : nullptr,
+                                         mb_workspace_->data(), sample->dev_edges.data(), sample->dev_nodes.data(),
+                                         mb_count_->data(), stream),
+                 "ammsb_minibatch_nonlink");
+  if (cfg_.async_launch) {
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_sampler_), static_cast<hipStream_t>(stream)), "hipEventRecord");
+    sampler_valid_ = true;
+  } else {
+    sample->queue.Finish();  // the neighbour sampler runs on its own queue
   }
-  const uint32_t m = static_cast<uint32_t>(cfg_.mini_batch_size);
-  const uint64_t u = host_rng_() % N;
-  ThrowIfError(ctx_.get(),
-               ammsb_minibatch_nonlink(ctx_.get(), mb_rand_->Get(), candidates_, static_cast<uint32_t>(u), m,
-                                       &trainingSet_->Get(), heldoutSet_ ? &heldoutSet_->Get() : nullptr,
-                                       mb_workspace_->data(), sample->dev_edges.data(), sample->dev_nodes.data(),
-                                       mb_count_->data(), stream),
-               "ammsb_minibatch_nonlink");
-  sampler_end();
-  if (!cfg_.async_launch) sample->queue.Finish();
-  sample->num_edges = m;
-  sample->num_nodes = m + 1;
+  sample->num_edges = ch.link ? ch.n : m;
+  sample->num_nodes = sample->num_edges + 1;
   sample->neighbor_sampler(sample->num_nodes, &sample->dev_nodes);
-  return static_cast<Float>(2 * cfg_.E) / static_cast<Float>(m);  // sample.cc:292
+  return ch.link ? static_cast<Float>(N)                                        // sample.cc:268
+                 : static_cast<Float>(2 * cfg_.E) / static_cast<Float>(m);      // sample.cc:292
+}
+
+Float Learner::DoSampleDevice(Sample* sample) {
+  const int idx = sample == samples_[0].get() ? 0 : 1;
+  choice_[idx] = ChooseDevice();
+  return EnqueueDevice(sample, choice_[idx]);
 }
 
 Float Learner::DoSample(Sample* sample) {
@@ -208,6 +310,56 @@ void Learner::RunAsync(uint32_t max_iters, sig_atomic_t* signaled) {
   }
 }
 
+// The same iterations as RunAsync, enqueued as captured graphs (ammsb_loop): the host only chooses the mini-batches
+// and hands them over; sizes, eps_t and weights travel in device descriptors.  Bit-identical to RunAsync.
+void Learner::RunGraph(uint32_t max_iters, sig_atomic_t* signaled) {
+  hipStream_t main = static_cast<hipStream_t>(queue_.stream());
+  if (phiUpdater_.CountCalls() != betaUpdater_.CountCalls()) throw std::runtime_error("graph_launch: step counters differ");
+  if (!enqueued_[phase_]) {  // the first mini-batch is sampled eagerly, as in RunAsync
+    Sample* s = samples_[phase_].get();
+    weights_[phase_] = DoSampleDevice(s);
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_ready_[phase_]), static_cast<hipStream_t>(s->queue.stream())),
+                  "hipEventRecord");
+    enqueued_[phase_] = true;
+  }
+  const uint32_t kChunk = 512;  // iterations between two looks at `signaled`
+  std::vector<ammsb_mb_choice> next;
+  uint32_t done = 0;
+  while (done < max_iters && (signaled ? !*signaled : true)) {
+    const uint32_t n = std::min(kChunk, max_iters - done);
+    clcuda::Check(hipStreamWaitEvent(main, static_cast<hipEvent_t>(ev_ready_[phase_]), 0), "hipStreamWaitEvent");
+    next.resize(n);
+    for (uint32_t i = 0; i < n; ++i) next[i] = ChooseDevice();
+    ThrowIfError(ctx_.get(),
+                 ammsb_loop_run(loop_, &choice_[phase_], next.data(), n, phiUpdater_.CountCalls() + 1,
+                                static_cast<uint32_t>(phase_), main),
+                 "ammsb_loop_run");
+    const uint32_t m = static_cast<uint32_t>(cfg_.mini_batch_size);
+    edges_done_ += choice_[phase_].link ? choice_[phase_].n : m;
+    for (uint32_t i = 0; i + 1 < n; ++i) edges_done_ += next[i].link ? next[i].n : m;
+    phiUpdater_.CountCalls() += n;
+    betaUpdater_.CountCalls() += n;
+    stepCount_ += n;
+    phase_ ^= static_cast<int>(n & 1u);
+    const ammsb_mb_choice& last = next.back();
+    choice_[phase_] = last;
+    samples_[phase_]->num_edges = last.link ? last.n : m;
+    samples_[phase_]->num_nodes = samples_[phase_]->num_edges + 1;
+    weights_[phase_] = last.link ? static_cast<Float>(cfg_.N) : static_cast<Float>(2 * cfg_.E) / static_cast<Float>(m);
+    enqueued_[phase_] = true;
+    enqueued_[1 - phase_] = false;
+    // everything queued on the main stream so far orders whatever the eager path does next
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_ready_[phase_]), main), "hipEventRecord");
+    for (int i = 0; i < 2; ++i) {
+      clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_consumed_[i]), main), "hipEventRecord");
+      consumed_valid_[i] = true;
+    }
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_sampler_), main), "hipEventRecord");
+    sampler_valid_ = true;
+    done += n;
+  }
+}
+
 void Learner::DrainAsync() {
   if (!cfg_.async_launch) return;
   for (auto& smp : samples_) smp->queue.Finish();
@@ -217,8 +369,12 @@ void Learner::DrainAsync() {
 void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
   const auto t1 = high_resolution_clock::now();
   if (cfg_.async_launch) {
-    RunAsync(max_iters, signaled);
+    if (loop_)
+      RunGraph(max_iters, signaled);
+    else
+      RunAsync(max_iters, signaled);
     DrainAsync();  // Run() returns with the work done, like the reference's
+    CheckDeviceSampler();
     time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
     return;
   }
@@ -234,6 +390,10 @@ void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
     betaUpdater_(&s.dev_edges, s.num_edges, weight);
     edges_done_ += s.num_edges;
     phase_ = 1 - phase_;
+  }
+  if (cfg_.device_sampling) {
+    if (futures_[phase_].valid()) futures_[phase_].wait();  // the pending sample's kernels are enqueued and finished
+    CheckDeviceSampler();
   }
   time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
 }
@@ -276,6 +436,7 @@ bool Learner::SerializeDeviceSampler(std::ostream* out) {
   std::ostringstream st;
   st << host_rng_ << " " << samples_[0]->num_edges << " " << samples_[0]->num_nodes << " " << samples_[1]->num_edges
      << " " << samples_[1]->num_nodes << " " << edges_done_;
+  for (const ammsb_mb_choice& ch : choice_) st << " " << ch.link << " " << ch.u << " " << ch.n << " " << ch.n_candidates;
   SampleStorage ext;  // reused as a two-bytes-field container: edges = magic, nodes_vec = text state
   ext.edges = "AMMSB-DEVSAMPLER-CPP-1";
   ext.nodes_vec = st.str();
@@ -289,6 +450,7 @@ bool Learner::ParseDeviceSampler(std::istream* in) {
   std::istringstream st(ext.nodes_vec);
   st >> host_rng_ >> samples_[0]->num_edges >> samples_[0]->num_nodes >> samples_[1]->num_edges >>
       samples_[1]->num_nodes >> edges_done_;
+  for (ammsb_mb_choice& ch : choice_) st >> ch.link >> ch.u >> ch.n >> ch.n_candidates;
   return !st.fail() && mb_rand_->Parse(in);
 }
 

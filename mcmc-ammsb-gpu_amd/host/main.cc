@@ -115,6 +115,7 @@ int main(int argc, char** argv) {
       Opt("sample-seed1", 0, &cfg.sample_seed[1], "846930886 (new)"),
       Opt("device-sampling", 0, &cfg.device_sampling, "0 (new: draw mini-batches on the device)"),
       Opt("async", 0, &cfg.async_launch, "0 (new: enqueue-only loop; needs --device-sampling 1)"),
+      Opt("graph", 0, &cfg.graph_launch, "0 (new: iterations as captured hipGraphs; needs --async 1)"),
       OptStr("checkpoint-in", 0, &ckptIn),    // (new) Learner::Parse before the first iteration
       OptStr("checkpoint-out", 0, &ckptOut),  // (new) Learner::Serialize after the last one
   };

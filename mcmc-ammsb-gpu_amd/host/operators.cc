@@ -159,7 +159,11 @@ Sample::Sample(const Config& cfg, clcuda::Queue q, unsigned int s)
       dev_nodes(q.GetContext(), MaxNodes(cfg)),
       seed(s),
       // async: one stream per sample carries its mini-batch kernels and its neighbour sampler in order
-      neighbor_sampler(cfg, cfg.async_launch ? queue : clcuda::Queue(q.GetContext(), q.GetDevice())) {}
+      neighbor_sampler(cfg, cfg.async_launch ? queue : clcuda::Queue(q.GetContext(), q.GetDevice())) {
+  // zeros: whatever a kernel reads from a not yet sampled buffer is a valid vertex id
+  clcuda::Check(hipMemset(dev_edges.data(), 0, dev_edges.Count() * sizeof(Edge)), "hipMemset");
+  clcuda::Check(hipMemset(dev_nodes.data(), 0, dev_nodes.Count() * sizeof(Vertex)), "hipMemset");
+}
 
 Sample::Sample(const Config& cfg, clcuda::Queue q) : Sample(cfg, q, static_cast<unsigned int>(rand())) {}
 

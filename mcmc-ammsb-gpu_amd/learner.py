@@ -72,6 +72,11 @@ class Config:
         self.phi_chunks = 4                          # (new) multi-GPU: phi launches per iteration (exchange overlap)
         self.phi_replicate = "auto"                  # (new) multi-GPU: fraction of groups every rank computes itself
         self.force_exchange = False                  # (new, tests) take the multi-rank code path even with one rank
+        # (new) whole iterations as captured hipGraphs (include/ammsb.h ammsb_loop): "auto" = whenever it applies
+        # (device sampling, one rank); False keeps the eager launch-by-launch loop (the parity form); results are
+        # bit-identical either way
+        self.graph_launch = "auto"
+        self.graph_timestamps = False                # (new) keep device time stamps around update_phi (bench.py)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown Config field %s" % k)
@@ -94,8 +99,8 @@ class Sample:
         self.stream = L.ops.new_stream(ctx)
         self.max_edges = ds.max_edges(cfg.mini_batch_size)
         self.max_nodes = ds.max_nodes(cfg.mini_batch_size)
-        self.dev_edges = ctx.empty((self.max_edges,), torch.int64)
-        self.dev_nodes = ctx.empty((self.max_nodes,), torch.int32)
+        self.dev_edges = ctx.zeros((self.max_edges,), torch.int64)   # zeros: whatever a kernel reads here is a valid id
+        self.dev_nodes = ctx.zeros((self.max_nodes,), torch.int32)
         self.pin_edges = L.ops.pinned((self.max_edges,), torch.int64)
         self.pin_nodes = L.ops.pinned((self.max_nodes,), torch.int32)
         self.seed = int(seed)
@@ -104,6 +109,7 @@ class Sample:
         self.n_edges = self.n_nodes = 0
         self.neighbor_sampler = L.ops.NeighborSampler(ctx, self.max_nodes, cfg.neighbor_seed,
                                                       cfg.neighbor_sampler_wg_size)
+        self.choice = None                   # device sampling: the (link, u, n, n_candidates) sitting in the buffers
         self.ready = L.ops.new_event()      # sampling finished (recorded on self.stream)
         self.consumed = L.ops.new_event()   # the iteration that used this sample finished (main stream)
         self.consumed_valid = False
@@ -154,6 +160,7 @@ class Learner:
         self.time = 0.0
         self.samplingTime = 0.0
         self.edges_done = 0
+        self.step_log = None  # a list here collects (n_edges, n_nodes) of every iteration (bench.py)
         self.samples = [Sample(self, cfg.sample_seeds[0])]
         if cfg.sample_parallel:
             self.samples.append(Sample(self, cfg.sample_seeds[1]))
@@ -161,10 +168,17 @@ class Learner:
         self.futures = [None, None]
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if not cfg.device_sampling else None
         self.dev_sampler = None
+        self.loop = None
         if cfg.device_sampling:
             off, tgt = dataset.training_csr()
+            # held-out links of a vertex are invalid non-link partners too (sample.cc:283-285)
+            he = np.ascontiguousarray(dataset.heldout_edges, dtype=np.uint64)
+            he = he[dataset.heldout.Has(he)] if he.size else he
+            ends = np.concatenate([he >> np.uint64(32), he & np.uint64(0xFFFFFFFF)]).astype(np.int64)
+            hdeg = np.bincount(ends, minlength=N)[:N]
             self.dev_sampler = ops.DeviceMiniBatchSampler(c, off, tgt, self.trainingSet, self.heldoutSet,
-                                                          cfg.mini_batch_size, cfg.device_sampling_seed)
+                                                          cfg.mini_batch_size, cfg.device_sampling_seed,
+                                                          heldout_degree=hdeg)
         if self.sharded:
             # the replicated groups run on their own stream next to the exchanged blocks: with 8 ranks a block is
             # ~1800 single-wave nodes, well under what the chip holds, and the two launches fill it together
@@ -181,6 +195,15 @@ class Learner:
         ops.synchronize()
         if self.sharded and cfg.phi_replicate == "auto":
             self._calibrate_split()
+        want_graph = cfg.graph_launch
+        can_graph = (self.dev_sampler is not None and not self.sharded and len(self.samples) == 2
+                     and hasattr(ops, "GraphLoop") and cfg.strategy in ("Node", "NodeLink", "NodeNonLink"))
+        if want_graph is True and not can_graph:
+            raise AmmsbError("graph_launch needs device sampling (Node strategies), sample_parallel and a single rank")
+        if want_graph in (True, "auto") and can_graph:
+            self.loop = ops.GraphLoop(c, self.theta, self.beta, self.pi, self.phi, self.trainingSet, self.heldoutSet,
+                                      self.phiUpdater, self.betaUpdater, self.samples, self.dev_sampler,
+                                      timestamps=bool(cfg.graph_timestamps))
 
     # ------------------------------------------------------------------ sampling (learner.cc:175-194)
 
@@ -191,7 +214,8 @@ class Learner:
             if sample.consumed_valid:
                 ops.wait_event(sample.consumed)  # do not overwrite buffers a running iteration still reads
             if self.dev_sampler is not None:
-                ne, nv, weight = self.dev_sampler(cfg.strategy, sample.dev_edges, sample.dev_nodes)
+                sample.choice = self.dev_sampler.choose(cfg.strategy)
+                ne, nv, weight = self.dev_sampler.enqueue(sample.choice, sample.dev_edges, sample.dev_nodes)
             else:
                 edges, nodes, weight, sample.seed = self.dataset.sample(cfg.mini_batch_size, cfg.strategy,
                                                                         sample.seed)
@@ -356,7 +380,59 @@ class Learner:
 
     def Run(self, max_iters, signaled=None):
         with self.ops.pin_current_stream():
-            self._run(max_iters, signaled)
+            if self.loop is not None:
+                self._run_graph(max_iters, signaled)
+            else:
+                self._run(max_iters, signaled)
+
+    GRAPH_CHUNK = 512  # iterations enqueued between two looks at `signaled`
+
+    def _run_graph(self, max_iters, signaled=None):
+        """The same iterations as _run, enqueued as captured graphs (ammsb_loop): the host only chooses the
+        mini-batches (link?, u) and hands them over; sizes, eps_t and weights travel in device descriptors."""
+        ops, cfg, smp = self.ops, self.cfg, self.dev_sampler
+        t1 = time.perf_counter()
+        phi, beta = self.phiUpdater, self.betaUpdater
+        if phi.count_calls != beta.count_calls:
+            raise AmmsbError("graph_launch: phi and beta step counters differ (%d, %d)" % (phi.count_calls, beta.count_calls))
+        if self.futures[self.phase] is None:
+            self._launch_sample(self.phase)   # the first mini-batch is sampled eagerly, as in _run
+        done = 0
+        while done < max_iters and not (signaled is not None and signaled()):
+            n = min(self.GRAPH_CHUNK, max_iters - done)
+            self.futures[self.phase].result()
+            s = self.samples[self.phase]
+            ops.wait_event(s.ready)
+            for o in self.samples:
+                if o.consumed_valid:
+                    ops.wait_event(o.consumed)
+            if s.choice is None:
+                raise AmmsbError("graph_launch: the pending mini-batch was not drawn by the device sampler")
+            nxt = [smp.choose(cfg.strategy) for _ in range(n)]
+            self.loop.run(s.choice, nxt, phi.count_calls + 1, self.phase)
+            consumed = [s.choice] + nxt[:-1]
+            self.edges_done += sum(smp.sizes(ch)[0] for ch in consumed)
+            if self.step_log is not None:
+                self.step_log.extend(smp.sizes(ch)[:2] for ch in consumed)
+            phi.count_calls += n
+            beta.count_calls += n
+            self.stepCount += n
+            self.phase ^= n & 1
+            # the new pending mini-batch sits in samples[phase]; everything queued so far orders the eager path
+            p = self.samples[self.phase]
+            p.choice = nxt[-1]
+            p.n_edges, p.n_nodes, w = smp.sizes(p.choice)
+            f = concurrent.futures.Future()
+            f.set_result(w)
+            self.futures[self.phase] = f
+            self.futures[1 - self.phase] = None
+            ops.record_event(p.ready)
+            for o in self.samples:
+                ops.record_event(o.consumed)
+                o.consumed_valid = True
+            smp.mark_used()
+            done += n
+        self.time += time.perf_counter() - t1
 
     def _run(self, max_iters, signaled=None):
         ops, cfg = self.ops, self.cfg
@@ -396,6 +472,8 @@ class Learner:
             ops.record_event(s.consumed)
             s.consumed_valid = True
             self.edges_done += n_edges
+            if self.step_log is not None:
+                self.step_log.append((n_edges, n_nodes))
             if nsamples == 2:
                 self.phase = 1 - self.phase
             it += 1
@@ -490,6 +568,8 @@ class Learner:
             self._launch_sample(self.phase)  # the reference's constructor has it in flight already
         weight = float(self.futures[self.phase].result()) if two else 0.0  # learner.cc:307-314
         self.ops.synchronize()
+        if self.dev_sampler is not None:
+            self.dev_sampler.check()
         ck.write_buffer(out, self.beta)
         ck.write_buffer(out, self.theta)
         ck.write_rpm(out, self.pi)
@@ -512,8 +592,9 @@ class Learner:
             self._sample_records(out, s)
         if self.dev_sampler is not None:
             import json
-            st = dict(rng=self.dev_sampler.host_rng.bit_generator.state,
-                      sizes=[[s.n_edges, s.n_nodes] for s in self.samples], edges_done=self.edges_done)
+            st = dict(self.dev_sampler.state(), sizes=[[s.n_edges, s.n_nodes] for s in self.samples],
+                      choices=[list(s.choice) if s.choice is not None else None for s in self.samples],
+                      edges_done=self.edges_done)
             ck.write_message(out, [(1, ck.BYTES, b"AMMSB-DEVSAMPLER-1"), (2, ck.BYTES, json.dumps(st).encode())])
             ck.write_buffer(out, self.dev_sampler.rand.seeds)
         return True
@@ -550,9 +631,10 @@ class Learner:
             if m[1] != b"AMMSB-DEVSAMPLER-1":
                 raise ck.CheckpointError("checkpoint has no device-sampler record")
             st = json.loads(m[2].decode())
-            self.dev_sampler.host_rng.bit_generator.state = st["rng"]
-            for s, (ne, nv) in zip(self.samples, st["sizes"]):
+            self.dev_sampler.load_state(st)
+            for s, (ne, nv), ch in zip(self.samples, st["sizes"], st.get("choices", [None, None])):
                 s.n_edges, s.n_nodes = int(ne), int(nv)
+                s.choice = tuple(int(x) for x in ch) if ch is not None else None
             self.edges_done = int(st["edges_done"])
             ck.read_buffer(inp, self.dev_sampler.rand.seeds)
         self.futures = [None, None]
@@ -569,6 +651,8 @@ class Learner:
             if f is not None:
                 f.result()
         self.ops.synchronize()
+        if self.dev_sampler is not None:
+            self.dev_sampler.check()  # a mini-batch that came up short is an error, never a silent duplicate
 
     def PrintStats(self, out=print):
         out("TOTAL    : %.6f" % self.time)
@@ -577,5 +661,8 @@ class Learner:
 
     def close(self):
         self.drain()
+        if self.loop is not None:
+            self.loop.close()
+            self.loop = None
         if self.pool is not None:
             self.pool.shutdown(wait=True)

@@ -16,6 +16,7 @@ stream and returns without synchronising (the reference calls queue.Finish() aft
 caller that wants that behaviour calls torch.cuda.synchronize()).
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -147,16 +148,17 @@ def to_numpy(t, dtype=None):
 class Random:
     """OpenClRandom: `size` xorshift128+ streams, stream i seeded {sx+i, sy+i} (random.cc:31-43)."""
 
-    def __init__(self, ctx, size, seed):
+    def __init__(self, ctx, size, seed, mixed=False):
         self.ctx = ctx
         self.size = int(size)
+        self.mixed = bool(mixed)  # SplitMix64-scrambled states (streams the reference does not have)
         self.seeds = ctx.empty((self.size, 2), torch.int64)
         self.SetSeed(seed)
 
     def SetSeed(self, seed):
         sx, sy = seed
-        self.ctx.check(self.ctx.lib.ammsb_rng_init(self.ctx.handle, _ptr(self.seeds), self.size,
-                                                   int(sx), int(sy), _stream()))
+        fn = self.ctx.lib.ammsb_rng_init_mixed if self.mixed else self.ctx.lib.ammsb_rng_init
+        self.ctx.check(fn(self.ctx.handle, _ptr(self.seeds), self.size, int(sx), int(sy), _stream()))
 
     def GetSeeds(self):
         return self.seeds
@@ -411,10 +413,20 @@ class DeviceMiniBatchSampler:
     """Device-side replacement for sampleNode + ExtractNodesFromMiniBatch (sample.cc:249-303,
     learner.cc:162-173).  The coin flip and the choice of u stay on the host (a numpy Generator), so
     the sizes of the mini-batch are known without reading anything back; the m distinct non-links /
-    the edges of u are produced on the device straight into the caller's edge and node buffers."""
+    the edges of u are produced on the device straight into the caller's edge and node buffers.
+
+    A mini-batch is first CHOSEN (`choose`: link?, u, deg(u), candidate draws) and then ENQUEUED
+    (`enqueue`, eager) or handed to the captured-graph loop (GraphLoop.run), so both paths consume the
+    same host stream of choices.  The number of candidate draws of a non-link batch follows the vertex:
+    enough for m + 1 + deg_training(u) + deg_heldout(u) distinct values (every invalid partner of u
+    could be drawn) plus the 8 % + 1024 margin, so a hub vertex cannot come up short.  A shortfall by
+    sheer bad luck is still detected: the device keeps a sticky counter that `check()` reads at the
+    learner's synchronisation points."""
+
+    BLOCK = 64  # choices drawn from the host generator at a time
 
     def __init__(self, ctx, csr_offsets, csr_targets, training_set, heldout_set, mini_batch, seed=(1234, 5678),
-                 host_seed=20260101):
+                 host_seed=20260101, heldout_degree=None):
         self.ctx = ctx
         self.m = int(mini_batch)
         self.N, self.E = int(ctx.params.N), int(ctx.params.E)
@@ -423,49 +435,177 @@ class DeviceMiniBatchSampler:
         self.degree = np.diff(off.astype(np.int64))
         if not (self.degree > 0).any():
             raise AmmsbError("training graph has no edges")
+        self.max_fan_out = int(self.degree.max())
+        self.excluded = self.degree + 1  # invalid partners of u: itself and its neighbours in both graphs
+        if heldout_degree is not None:
+            self.excluded = self.excluded + np.asarray(heldout_degree, dtype=np.int64)
         self.offsets = ctx.from_numpy(off)
         self.targets = ctx.from_numpy(np.ascontiguousarray(csr_targets, dtype=np.uint32))
-        self.C = int(ctx.lib.ammsb_minibatch_candidates(self.N, self.m))
+        self._cand = {}
+        self.C = self._candidates_for(int(self.excluded.max()))  # capacity: streams and workspace
         if self.C == 0:
-            raise AmmsbError("device sampling needs N >= 2 * mini_batch (N=%d, m=%d)" % (self.N, self.m))
-        self.rand = Random(ctx, self.C, seed)
-        self.workspace = ctx.empty((int(ctx.lib.ammsb_minibatch_workspace_bytes(self.C)),), torch.uint8)
-        self.count = ctx.zeros((1,), torch.int32)
+            raise AmmsbError("device sampling needs N >= 2 * mini_batch with room for the largest degree "
+                             "(N=%d, m=%d, max excluded=%d)" % (self.N, self.m, int(self.excluded.max())))
+        self.rand = Random(ctx, self.C, seed, mixed=True)
+        # 0xFF once: every call leaves the de-duplication table empty again (include/ammsb.h)
+        self.workspace = torch.full((int(ctx.lib.ammsb_minibatch_workspace_bytes(self.C)),), 255, dtype=torch.uint8,
+                                    device=ctx.device)
+        self.count = ctx.zeros((2,), torch.int32)  # [0] distinct candidates of the last call, [1] sticky shortfalls
         self.host_rng = np.random.default_rng(host_seed)
+        self.queue = []  # choices drawn ahead, BLOCK at a time: (coin, u) pairs not yet consumed
+        self.w_link = float(np.float32(self.N))                               # sample.cc:268
+        self.w_nonlink = float(np.float32(2 * self.E) / np.float32(self.m))   # sample.cc:292
         # The candidate streams, the workspace and the counter are shared by successive calls, which the learner
         # issues on two alternating streams: each call waits for the previous one's kernels before it starts.
         self._done = torch.cuda.Event()
         self._done_valid = False
 
-    def __call__(self, strategy, dev_edges, dev_nodes):
-        """Enqueue one mini-batch; returns (n_edges, n_nodes, weight)."""
-        c = self.ctx
+    def _candidates_for(self, excluded):
+        key = (int(excluded) + 255) // 256 * 256  # few distinct values
+        c = self._cand.get(key)
+        if c is None:
+            c = self._cand[key] = int(self.ctx.lib.ammsb_minibatch_candidates_for(self.N, self.m, key))
+        return c
+
+    def _refill(self):
+        coins = self.host_rng.integers(0, 2, size=self.BLOCK)  # rand_r(seed) % 2, sample.cc:297
+        us = self.host_rng.integers(0, self.N, size=self.BLOCK)
+        self.queue = list(zip(coins.tolist(), us.tolist()))[::-1]
+
+    def choose(self, strategy):
+        """The next mini-batch: (link, u, n, n_candidates)."""
         link = {"Node": None, "NodeLink": True, "NodeNonLink": False}.get(strategy, "bad")
         if link == "bad":
             raise AmmsbError("device sampling implements Node / NodeLink / NodeNonLink only")
+        while True:
+            if not self.queue:
+                self._refill()
+            coin, u = self.queue.pop()
+            is_link = bool(coin) if link is None else link
+            if is_link:
+                n = int(self.degree[u])
+                if n == 0:  # sampleNodeLink retries until the vertex has an edge (sample.cc:254-263)
+                    while True:
+                        if not self.queue:
+                            self._refill()
+                        u = self.queue.pop()[1]
+                        n = int(self.degree[u])
+                        if n > 0:
+                            break
+                return (1, u, n, 0)
+            return (0, u, 0, self._candidates_for(self.excluded[u]))
+
+    def sizes(self, choice):
+        """(n_edges, n_nodes, weight) of a choice."""
+        link, u, n, _ = choice
+        if link:
+            return n, n + 1, self.w_link
+        return self.m, self.m + 1, self.w_nonlink
+
+    def enqueue(self, choice, dev_edges, dev_nodes):
+        """Eager form: enqueue the kernels of one chosen mini-batch on the current stream."""
+        c = self.ctx
         if self._done_valid:
             self._done.wait()
-        if link is None:
-            link = bool(self.host_rng.integers(0, 2))  # rand_r(seed) % 2, sample.cc:297
+        link, u, n, n_cand = choice
         if link:
-            while True:  # sampleNodeLink retries until the vertex has an edge (sample.cc:254-263)
-                u = int(self.host_rng.integers(0, self.N))
-                if self.degree[u] > 0:
-                    break
-            n = int(self.degree[u])
             c.check(c.lib.ammsb_minibatch_link(c.handle, _ptr(self.offsets), _ptr(self.targets), u, n,
                                                _ptr(dev_edges), _ptr(dev_nodes), _stream()))
-            self._done.record()
-            self._done_valid = True
-            return n, n + 1, float(np.float32(self.N))
-        u = int(self.host_rng.integers(0, self.N))
-        hs = C.byref(self.heldout_set.desc) if self.heldout_set is not None else None
-        c.check(c.lib.ammsb_minibatch_nonlink(c.handle, _ptr(self.rand.seeds), self.C, u, self.m,
-                                              C.byref(self.training_set.desc), hs, _ptr(self.workspace),
-                                              _ptr(dev_edges), _ptr(dev_nodes), _ptr(self.count), _stream()))
+        else:
+            hs = C.byref(self.heldout_set.desc) if self.heldout_set is not None else None
+            c.check(c.lib.ammsb_minibatch_nonlink(c.handle, _ptr(self.rand.seeds), n_cand, self.C, u, self.m,
+                                                  C.byref(self.training_set.desc), hs, _ptr(self.workspace),
+                                                  _ptr(dev_edges), _ptr(dev_nodes), _ptr(self.count), _stream()))
         self._done.record()
         self._done_valid = True
-        return self.m, self.m + 1, float(np.float32(2 * self.E) / np.float32(self.m))  # sample.cc:292
+        return self.sizes(choice)
+
+    def __call__(self, strategy, dev_edges, dev_nodes):
+        """Choose and enqueue one mini-batch; returns (n_edges, n_nodes, weight)."""
+        return self.enqueue(self.choose(strategy), dev_edges, dev_nodes)
+
+    def mark_used(self):
+        """The shared sampler state was just used by work queued on the current stream (a graph run)."""
+        self._done.record()
+        self._done_valid = True
+
+    def check(self):
+        """Raise if any non-link mini-batch since the last check found fewer than m distinct valid partners
+        (its tail then repeats earlier entries: not a valid sample).  Synchronises; call at sync points."""
+        short = int(self.count[1].item())
+        if short:
+            self.count[1].zero_()
+            raise AmmsbError("device mini-batch sampler: %d mini-batch(es) found fewer than %d distinct non-links "
+                             "(last count %d)" % (short, self.m, int(self.count[0].item())))
+
+    def state(self):
+        return dict(rng=self.host_rng.bit_generator.state, queue=[[int(a), int(b)] for a, b in self.queue])
+
+    def load_state(self, st):
+        self.host_rng.bit_generator.state = st["rng"]
+        self.queue = [(int(a), int(b)) for a, b in st.get("queue", [])]
+
+
+class GraphLoop:
+    """ammsb_loop (include/ammsb.h): whole iterations replayed as captured hipGraphs over a Learner's buffers."""
+
+    def __init__(self, ctx, theta, beta, pi, phi_sum, training_set, heldout_set, phi, beta_upd, samples, sampler,
+                 timestamps=False):
+        self.ctx = ctx
+        cfg = _capi.LoopConfig()
+        cfg.theta, cfg.beta = theta.data_ptr(), beta.data_ptr()
+        cfg.pi = C.pointer(pi.desc)
+        cfg.phi_sum = phi_sum.data_ptr()
+        cfg.training_set = C.pointer(training_set.desc)
+        cfg.heldout_set = C.pointer(heldout_set.desc) if heldout_set is not None else None
+        cfg.phi_seeds, cfg.phi_vec = phi.rand.seeds.data_ptr(), phi.phi_vec.data_ptr()
+        cfg.phi_wg, cfg.phi_flags = phi.local, phi.flags
+        cfg.beta_seeds, cfg.grads = beta_upd.rand.seeds.data_ptr(), beta_upd.grads.data_ptr()
+        cfg.beta_wg, cfg.beta_flags = beta_upd.local, beta_upd.flags
+        for i, s in enumerate(samples):
+            ns = s.neighbor_sampler
+            cfg.edges[i], cfg.nodes[i] = s.dev_edges.data_ptr(), s.dev_nodes.data_ptr()
+            cfg.neighbors[i], cfg.nbr_table[i] = ns.data.data_ptr(), ns.hash.data_ptr()
+            cfg.nbr_seeds[i] = ns.rand.seeds.data_ptr()
+        cfg.nbr_wg = samples[0].neighbor_sampler.local
+        cfg.csr_offsets, cfg.csr_targets = sampler.offsets.data_ptr(), sampler.targets.data_ptr()
+        cfg.mb_seeds, cfg.mb_candidates = sampler.rand.seeds.data_ptr(), sampler.C
+        cfg.mb_workspace, cfg.mb_count = sampler.workspace.data_ptr(), sampler.count.data_ptr()
+        cfg.mini_batch, cfg.max_fan_out = sampler.m, sampler.max_fan_out
+        cfg.flags = (_capi.LOOP_TIMESTAMPS if timestamps else 0) | (2 if os.environ.get("AMMSB_LOOP_SERIAL") else 0)
+        self.timestamps_on = bool(timestamps)
+        self._keep = (theta, beta, pi, phi_sum, training_set, heldout_set, phi, beta_upd, samples, sampler)
+        self._h = C.c_void_p()
+        torch.cuda.synchronize()  # the captured kernels' buffers are initialised before anything replays
+        ctx.check(ctx.lib.ammsb_loop_create(ctx.handle, C.byref(cfg), C.byref(self._h)))
+
+    def run(self, pending, nxt, first_step, parity):
+        n = len(nxt)
+        arr = (_capi.MbChoice * max(n, 1))()
+        for i, ch in enumerate(nxt):
+            arr[i].link, arr[i].u, arr[i].n, arr[i].n_candidates = ch
+        pend = _capi.MbChoice(*pending)
+        self.ctx.check(self.ctx.lib.ammsb_loop_run(self._h, C.byref(pend), arr, n, int(first_step), int(parity),
+                                                   _stream()))
+
+    def timestamps(self, first_step, n):
+        """(begin_ns, end_ns) arrays of update_phi for steps first_step .. first_step + n - 1.  Synchronises."""
+        b, e = np.zeros(n, dtype=np.float64), np.zeros(n, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self.ctx.check(self.ctx.lib.ammsb_loop_timestamps(self._h, int(first_step), int(n), b.ctypes.data_as(dp),
+                                                          e.ctypes.data_as(dp)))
+        return b, e
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.ammsb_loop_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- stream / event / collective plumbing used by learner.py (torch is the transport only)

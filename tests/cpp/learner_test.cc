@@ -31,10 +31,11 @@ struct RunResult {
 };
 
 static RunResult RunOnce(uint64_t N, const std::vector<mcmc::Edge>& edges, uint32_t iters, bool device_sampling = false,
-                         bool async = false) {
+                         bool async = false, bool graph = false) {
   mcmc::Config cfg;
   cfg.device_sampling = device_sampling;
   cfg.async_launch = async;
+  cfg.graph_launch = graph;
   cfg.N = N;
   cfg.K = 64;
   cfg.mini_batch_size = 256;
@@ -130,6 +131,7 @@ static int CheckpointMode(const std::string& mode, const std::string& dir) {
   FillConfig(&cfg, N);
   cfg.device_sampling = getenv("AMMSB_TEST_DEVICE_SAMPLING") != nullptr;  // C++-only end-to-end variant
   cfg.async_launch = getenv("AMMSB_TEST_ASYNC") != nullptr;
+  cfg.graph_launch = getenv("AMMSB_TEST_GRAPH") != nullptr;
   std::vector<mcmc::Edge> e;
   if (mode == "ckpt") {
     e = mcmc::GenerateSyntheticGraph(N, 16, 16, 7);
@@ -217,6 +219,10 @@ int main(int argc, char** argv) {
   // enqueue-only loop (Config::async_launch): same launches in the same order => the same bits
   const RunResult e = RunOnce(N, edges, 300, true, true);
   EXPECT(e.p1 == c.p1 && e.p2 == c.p2 && e.beta == c.beta && e.row == c.row);
+  // whole iterations as captured hipGraphs (Config::graph_launch): the same kernels again => the same bits
+  const RunResult g = RunOnce(N, edges, 300, true, true, true);
+  printf("ppx (graph launch): %.6f -> %.6f -> %.6f\n", g.p0, g.p1, g.p2);
+  EXPECT(g.p1 == c.p1 && g.p2 == c.p2 && g.beta == c.beta && g.row == c.row);
   double s = 0;
   for (float v : a.row) s += v;
   EXPECT(std::fabs(s - 1.0) < 1e-4);

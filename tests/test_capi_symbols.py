@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(capi):
 
 def test_host_only_entry_points(capi, orc):
     lib = capi.load()
-    assert lib.ammsb_version() == 100
+    assert lib.ammsb_version() == 200
     assert lib.ammsb_strerror(0) == b"ok" and lib.ammsb_strerror(-1) == b"invalid argument"
     p = capi.Params(1000, 48, 0, 32, 1.0 / 48, 0.0315, 1024.0, 0.5, 1e-7, 1.0, 1.0)
     assert lib.ammsb_params_quantize(C.byref(p)) == 0

@@ -228,7 +228,7 @@ def test_c5_full_size(env, orc):
     assert (ne, nv) == (m, m + 1)
     s.neighbor_sampler(nv, s.dev_nodes)
     torch.cuda.synchronize()
-    assert int(lrn.dev_sampler.count.cpu()) >= m
+    assert int(lrn.dev_sampler.count[0].cpu()) >= m and int(lrn.dev_sampler.count[1].cpu()) == 0
     nodes_h = s.dev_nodes[:nv].cpu().numpy().view(np.uint32).copy()
     nbrs = s.neighbor_sampler.GetData()
     nbrs_h = nbrs[:nv].cpu().numpy().view(np.uint32).copy()

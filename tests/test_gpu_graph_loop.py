@@ -1,0 +1,184 @@
+"""The captured-graph iteration (include/ammsb.h ammsb_loop) against the eager launch-by-launch loop: same
+kernels, same arguments, same per-stream order => bit-identical trajectories.  Plus the device mini-batch
+sampler's guarantees that the graph path relies on (per-vertex candidate counts, visible shortfalls)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import __graft_entry__ as ge
+    ge.build()
+    from mcmc_ammsb_gpu_amd import hostlib, learner, ops
+    return ops, hostlib, learner, torch
+
+
+@pytest.fixture(scope="module")
+def small_ds(env):
+    ops, hostlib, learner, torch = env
+    N = 20000
+    edges = hostlib.generate_graph(N, 16, 16, seed=7)
+    return hostlib.Dataset.robust(N, edges, heldout_ratio=0.02, rand_seed=3)
+
+
+def _state(ops, lrn):
+    lrn.drain()
+    return dict(pi=lrn.pi.host().copy(), phi=ops.to_numpy(lrn.phi).copy(), theta=ops.to_numpy(lrn.theta).copy(),
+                beta=ops.to_numpy(lrn.beta).copy(), phi_seeds=lrn.phiUpdater.rand.host(),
+                beta_seeds=lrn.betaUpdater.rand.host(), mb_seeds=lrn.dev_sampler.rand.host(),
+                nbr_seeds=[s.neighbor_sampler.rand.host() for s in lrn.samples],
+                step=lrn.stepCount, edges=lrn.edges_done, phase=lrn.phase,
+                calls=(lrn.phiUpdater.count_calls, lrn.betaUpdater.count_calls))
+
+
+def _same(a, b):
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+        elif isinstance(a[k], list):
+            assert all(np.array_equal(x, y) for x, y in zip(a[k], b[k])), k
+        else:
+            assert a[k] == b[k], (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("K,wg,m,strategy", [(64, 64, 256, "Node"),      # register kernels (one column per lane)
+                                              (256, 64, 512, "Node"),     # LDS-streamed kernels <4, 1>
+                                              (256, 64, 512, "NodeLink"),  # link batches only: device-read sizes
+                                              (32, 32, 1024, "NodeNonLink")])
+def test_graph_loop_equals_eager_loop(env, small_ds, K, wg, m, strategy):
+    ops, hostlib, learner, torch = env
+
+    def make(graph):
+        cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=16, strategy=strategy,
+                                               phi_wg_size=wg, beta_wg_size=wg, ppx_wg_size=wg, device_sampling=True,
+                                               graph_launch=graph)
+        return learner.Learner(cfg, small_ds)
+    eager, graph = make(False), make(True)
+    assert eager.loop is None and graph.loop is not None
+    for n in (1, 2, 37):
+        eager.Run(n)
+        graph.Run(n)
+        _same(_state(ops, eager), _state(ops, graph))
+        assert eager.HeldoutPerplexity() == graph.HeldoutPerplexity()
+    eager.close(), graph.close()
+
+
+def test_graph_and_eager_steps_interleave(env, small_ds):
+    """Run() calls may alternate between the two forms on one learner (the pending mini-batch, the sample
+    buffers' parity and every stream state carry over): eager 5 + graph 6 + eager 4 + graph 1 == eager 16."""
+    ops, hostlib, learner, torch = env
+
+    def make(graph):
+        cfg = learner.Config.from_cli_defaults(K=128, mini_batch_size=384, num_node_sample=8, strategy="Node",
+                                               phi_wg_size=64, beta_wg_size=64, ppx_wg_size=64, device_sampling=True,
+                                               graph_launch=graph)
+        return learner.Learner(cfg, small_ds)
+    ref, mix = make(False), make(True)
+    ref.Run(16)
+    loop = mix.loop
+    for n, use_graph in ((5, False), (6, True), (4, False), (1, True)):
+        mix.loop = loop if use_graph else None
+        mix.Run(n)
+    mix.loop = loop
+    _same(_state(ops, ref), _state(ops, mix))
+    assert ref.HeldoutPerplexity() == mix.HeldoutPerplexity()
+    ref.close(), mix.close()
+
+
+def test_graph_loop_many_steps_and_chunks(env, small_ds):
+    """More steps than one descriptor upload holds (1024) and than one Run() chunk (512)."""
+    ops, hostlib, learner, torch = env
+
+    def make(graph):
+        cfg = learner.Config.from_cli_defaults(K=32, mini_batch_size=128, num_node_sample=8, strategy="Node",
+                                               phi_wg_size=32, beta_wg_size=32, ppx_wg_size=32, device_sampling=True,
+                                               graph_launch=graph)
+        return learner.Learner(cfg, small_ds)
+    eager, graph = make(False), make(True)
+    graph.GRAPH_CHUNK = 1500  # one ammsb_loop_run call spanning two descriptor uploads
+    eager.Run(2100)
+    graph.Run(2100)
+    _same(_state(ops, eager), _state(ops, graph))
+    eager.close(), graph.close()
+
+
+def test_graph_loop_timestamps(env, small_ds):
+    ops, hostlib, learner, torch = env
+    cfg = learner.Config.from_cli_defaults(K=256, mini_batch_size=2048, num_node_sample=16, strategy="NodeNonLink",
+                                           phi_wg_size=64, beta_wg_size=64, ppx_wg_size=64, device_sampling=True,
+                                           graph_launch=True, graph_timestamps=True)
+    lrn = learner.Learner(cfg, small_ds)
+    lrn.Run(20)
+    b, e = lrn.loop.timestamps(1, 20)
+    d = e - b
+    assert (d > 0).all() and (d < 5e6).all()          # update_phi of 2049 nodes: microseconds, not milliseconds
+    assert (b[1:] > e[:-1]).all()                     # steps run one after the other
+    lrn.close()
+
+
+def _sampler(env, ds, m):
+    ops, hostlib, learner, torch = env
+    p = ops.make_params(ds.N, 32, E=ds.E, num_node_sample=8)
+    ctx = ops.Context(p)
+    ts = ops.DeviceSet(ctx, ds.training.Serialize(), ds.training.BinsPerBucket(), ds.training.PrimeIdx())
+    hs = ops.DeviceSet(ctx, ds.heldout.Serialize(), ds.heldout.BinsPerBucket(), ds.heldout.PrimeIdx())
+    off, tgt = ds.training_csr()
+    he = ds.heldout_edges[ds.heldout.Has(ds.heldout_edges)]
+    hdeg = np.bincount(np.concatenate([he >> np.uint64(32), he & np.uint64(0xFFFFFFFF)]).astype(np.int64),
+                       minlength=ds.N)
+    smp = ops.DeviceMiniBatchSampler(ctx, off, tgt, ts, hs, m, seed=(1234, 5678), host_seed=5, heldout_degree=hdeg)
+    e = ctx.empty((max(ds.max_edges(m), m),), torch.int64)
+    v = ctx.empty((ds.max_nodes(m),), torch.int32)
+    return ctx, smp, e, v
+
+
+def test_hub_vertex_gets_enough_candidates(env):
+    """a vertex with more neighbours than the sampler's margin (0.08 m + 1024) used to come up short
+    and the mini-batch was silently padded with duplicates.  The candidate count now follows the vertex."""
+    ops, hostlib, learner, torch = env
+    N, m, hub = 40000, 2048, 17
+    rng = np.random.default_rng(3)
+    spokes = rng.permutation(N)[:6000]
+    spokes = spokes[spokes != hub].astype(np.uint64)                   # degree ~6000 >> 0.08 * 2048 + 1024 = 1188
+    star = (np.minimum(spokes, np.uint64(hub)) << np.uint64(32)) | np.maximum(spokes, np.uint64(hub))
+    edges = np.unique(np.concatenate([star, hostlib.generate_graph(N, 16, 8, seed=11)]))
+    rng.shuffle(edges)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.02, rand_seed=3)
+    ctx, smp, e, v = _sampler(env, ds, m)
+    assert smp.excluded[hub] > 0.08 * m + 1024
+    small = smp._candidates_for(1)
+    mine = smp._candidates_for(smp.excluded[hub])
+    assert small < mine <= smp.C
+    ne, nv, w = smp.enqueue((0, hub, 0, mine), e, v)
+    torch.cuda.synchronize()
+    smp.check()
+    assert int(smp.count[0]) >= m
+    eh = e[:m].cpu().numpy().view(np.uint64)
+    vh = v[:m + 1].cpu().numpy().view(np.uint32)
+    assert vh[0] == hub and np.unique(vh).size == m + 1 and np.unique(eh).size == m   # no duplicate nodes
+    assert not ds.training.Has(eh).any() and not ds.heldout.Has(eh).any()
+    # with the old fixed count the same vertex does come up short -- and that is now an error, not a silent pad
+    smp.enqueue((0, hub, 0, small), e, v)
+    torch.cuda.synchronize()
+    if int(smp.count[0]) < m:
+        with pytest.raises(ops.AmmsbError):
+            smp.check()
+    smp.check()  # the sticky counter is cleared by the failed check
+    ctx.close()
+
+
+def test_short_minibatch_is_reported(env, small_ds):
+    ops, hostlib, learner, torch = env
+    m = 2048
+    ctx, smp, e, v = _sampler(env, small_ds, m)
+    smp.enqueue((0, 5, 0, m), e, v)      # m candidates can never give m distinct valid partners
+    torch.cuda.synchronize()
+    assert int(smp.count[0]) < m and int(smp.count[1]) == 1
+    with pytest.raises(ops.AmmsbError):
+        smp.check()
+    ctx.close()

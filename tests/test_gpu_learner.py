@@ -67,7 +67,7 @@ def test_device_minibatch_sampler(env, small_ds):
             saw.add("non")
             assert ne == m and nv == m + 1 and not link.any() and not ds.heldout.Has(eh).any()
             assert w == float(np.float32(2 * ds.E) / np.float32(m))
-            assert int(a.count.cpu()) >= m  # enough distinct candidates survived
+            assert int(a.count[0].cpu()) >= m and int(a.count[1].cpu()) == 0  # enough distinct candidates survived
     assert saw == {"link", "non"}
     # uniformity of the non-link partner (chi-square on 16 buckets over several draws)
     hist = np.zeros(16)
@@ -204,7 +204,7 @@ def test_checkpoint_cpp_python_round_trip(env, tmp_path):
     assert bits("cpp_from_py_ppx.txt") == want
 
 
-@pytest.mark.parametrize("async_launch", [False, True])
+@pytest.mark.parametrize("async_launch", [False, True, "graph"])
 def test_cpp_checkpoint_with_device_sampling(env, tmp_path, async_launch):
     """serialize-test.cc:90-134 for the C++ Learner with Config::device_sampling: the trailing extension record
     (host generator, batch sizes, candidate streams) makes the resumed run bit-identical."""
@@ -212,7 +212,8 @@ def test_cpp_checkpoint_with_device_sampling(env, tmp_path, async_launch):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mcmc-ammsb-gpu_amd", "learner_test")
     out = subprocess.run([exe, "ckpt", str(tmp_path)], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, AMMSB_TEST_DEVICE_SAMPLING="1", **({"AMMSB_TEST_ASYNC": "1"} if async_launch else {})))
+                         env=dict(os.environ, AMMSB_TEST_DEVICE_SAMPLING="1", **({"AMMSB_TEST_ASYNC": "1"} if async_launch else {}),
+                                  **({"AMMSB_TEST_GRAPH": "1"} if async_launch == "graph" else {})))
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
