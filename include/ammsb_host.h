@@ -58,10 +58,12 @@ int ammsb_host_theta_init(uint64_t K, float eta0, float eta1, float* theta_out);
 /* host mini-batch sampling (sample.cc:177-303 + learner.cc:162-173).  strategy: 0 Node, 1 NodeLink,
  * 2 NodeNonLink, 3 BFLink, 4 BFNonLink, 5 BF.  *seed is the rand_r state (Sample::seed).  edges_out
  * must hold max(mini_batch, max_fan_out) keys, nodes_out max(2*mini_batch, 1+max_fan_out) ids.
- * Returns 0; writes counts and the mini-batch weight. */
+ * edges_cap / nodes_cap are the capacities of the two arrays: a mini-batch that does not fit is NOT copied; the call
+ * returns -2 with the needed sizes in n_edges / n_nodes (the reference aborts with "N | cap", learner.cc:184-189).
+ * Returns 0 on success; writes counts and the mini-batch weight. */
 int ammsb_host_sample(const ammsb_host_dataset* d, uint64_t N, uint64_t E, uint64_t mini_batch, int strategy,
-                      unsigned* seed, uint64_t* edges_out, uint64_t* n_edges, uint32_t* nodes_out,
-                      uint64_t* n_nodes, float* weight);
+                      unsigned* seed, uint64_t* edges_out, uint64_t edges_cap, uint64_t* n_edges, uint32_t* nodes_out,
+                      uint64_t nodes_cap, uint64_t* n_nodes, float* weight);
 
 #ifdef __cplusplus
 }

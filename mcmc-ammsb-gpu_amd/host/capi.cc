@@ -136,8 +136,8 @@ int ammsb_host_theta_init(uint64_t K, float eta0, float eta1, float* theta_out) 
 }
 
 int ammsb_host_sample(const ammsb_host_dataset* d, uint64_t N, uint64_t E, uint64_t mini_batch, int strategy,
-                      unsigned* seed, uint64_t* edges_out, uint64_t* n_edges, uint32_t* nodes_out,
-                      uint64_t* n_nodes, float* weight) {
+                      unsigned* seed, uint64_t* edges_out, uint64_t edges_cap, uint64_t* n_edges, uint32_t* nodes_out,
+                      uint64_t nodes_cap, uint64_t* n_nodes, float* weight) {
   if (!d || !seed || !edges_out || !n_edges || !nodes_out || !n_nodes || !weight) return -1;
   if (strategy < 0 || strategy > 5) return -1;
   // the samplers read N, E, mini_batch_size and the data half of the Config
@@ -149,10 +149,11 @@ int ammsb_host_sample(const ammsb_host_dataset* d, uint64_t N, uint64_t E, uint6
   *weight = mcmc::GetSampler(static_cast<mcmc::SampleStrategy>(strategy))(cfg, &edges, seed);
   std::vector<mcmc::Vertex> nodes;
   mcmc::ExtractNodesFromMiniBatch(edges, &nodes);
-  memcpy(edges_out, edges.data(), sizeof(uint64_t) * edges.size());
-  memcpy(nodes_out, nodes.data(), sizeof(uint32_t) * nodes.size());
   *n_edges = edges.size();
   *n_nodes = nodes.size();
+  if (edges.size() > edges_cap || nodes.size() > nodes_cap) return -2;  // learner.cc:184-189 "N | cap"
+  memcpy(edges_out, edges.data(), sizeof(uint64_t) * edges.size());
+  memcpy(nodes_out, nodes.data(), sizeof(uint32_t) * nodes.size());
   return 0;
 }
 

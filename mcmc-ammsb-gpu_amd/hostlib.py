@@ -8,7 +8,7 @@ import numpy as np
 from ._capi import AmmsbError, load as _load_hip
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libammsb_host.so")
+LIB_PATH = os.environ.get("AMMSB_HOST_LIB") or os.path.join(_HERE, "libammsb_host.so")  # override: sanitizer build
 
 STRATEGIES = {"Node": 0, "NodeLink": 1, "NodeNonLink": 2, "BFLink": 3, "BFNonLink": 4, "BF": 5}
 
@@ -43,8 +43,8 @@ SIGNATURES = {
     "ammsb_host_dataset_training_csr": (C.c_int, [_vp, _u64p, _u32p]),
     "ammsb_host_theta_init": (C.c_int, [_u64, C.c_float, C.c_float,
                                         np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]),
-    "ammsb_host_sample": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, C.POINTER(C.c_uint), _u64p,
-                                    C.POINTER(_u64), _u32p, C.POINTER(_u64), C.POINTER(C.c_float)]),
+    "ammsb_host_sample": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, C.POINTER(C.c_uint), _u64p, _u64,
+                                    C.POINTER(_u64), _u32p, _u64, C.POINTER(_u64), C.POINTER(C.c_float)]),
 }
 
 _lib = None
@@ -208,11 +208,13 @@ class Dataset:
     def sample(self, mini_batch, strategy, seed):
         """One host mini-batch: returns (edges, nodes, weight, new_seed) -- DoSample's host half
         (learner.cc:175-185)."""
-        e = np.zeros(self.max_edges(mini_batch) + 1, dtype=np.uint64)
-        v = np.zeros(self.max_nodes(mini_batch) + 1, dtype=np.uint32)
+        e = np.zeros(self.max_edges(mini_batch), dtype=np.uint64)
+        v = np.zeros(self.max_nodes(mini_batch), dtype=np.uint32)
         ne, nv, w, s = _u64(), _u64(), C.c_float(), C.c_uint(seed)
         rc = self.lib.ammsb_host_sample(self._h, self.N, self.E, mini_batch, STRATEGIES[strategy], C.byref(s),
-                                        e, C.byref(ne), v, C.byref(nv), C.byref(w))
+                                        e, e.size, C.byref(ne), v, v.size, C.byref(nv), C.byref(w))
+        if rc == -2:  # learner.cc:184-189: the mini-batch does not fit the device buffers sized by the reference rule
+            raise AmmsbError("%d | %d (edges), %d | %d (nodes)" % (ne.value, e.size, nv.value, v.size))
         if rc != 0:
             raise AmmsbError("host sampler failed")
         return e[:ne.value].copy(), v[:nv.value].copy(), float(w.value), int(s.value)

@@ -140,6 +140,18 @@ void orc_perplexity(const orc_params_t* p, const float* beta, const float* pi,
                     orc_ppx_sums_t* out);
 double orc_ppx_value(const orc_ppx_sums_t* s); /* perplexity.cc:264-273 -> -avg ; learner.cc:196-203 exp */
 
+/* ---- host mini-batch samplers: sample.cc:177-303 + learner.cc:162-173 (ammsb_oracle_samplers.c) ---- */
+/* iteration order of a libstdc++ std::unordered_set<uint64_t> after inserting keys[0..n) one by one (restated
+ * container; test entry).  Returns the number of distinct keys written to out. */
+uint64_t orc_uset_order(const uint64_t* keys, uint64_t n, uint64_t* out);
+/* strategy: 0 Node, 1 NodeLink, 2 NodeNonLink, 3 BFLink, 4 BFNonLink, 5 BF.  ho_slots may be NULL.  Returns 0, or
+ * -1 (bad argument / an output array too small: n_edges, n_nodes then hold the needed sizes). */
+int orc_host_sample(uint64_t N, uint64_t E, uint64_t mini_batch, int strategy, unsigned int* seed,
+                    const uint64_t* training_edges, uint64_t n_training, const uint64_t* tr_slots, uint64_t tr_bins,
+                    uint32_t tr_prime, const uint64_t* ho_slots, uint64_t ho_bins, uint32_t ho_prime,
+                    uint64_t* edges_out, uint64_t edges_cap, uint64_t* n_edges, uint32_t* nodes_out,
+                    uint64_t nodes_cap, uint64_t* n_nodes, float* weight);
+
 /* number of OpenMP threads the library will use (1 if built without OpenMP) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

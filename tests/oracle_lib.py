@@ -52,7 +52,7 @@ def lib(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    so = path or os.path.join(ORACLE_DIR, "libammsb_oracle.so")
+    so = path or os.environ.get("AMMSB_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libammsb_oracle.so")  # override: sanitizer build
     if not os.path.exists(so):
         build(so)
     L = C.CDLL(so)
@@ -211,3 +211,43 @@ def sample_neighbors(seeds, nodes, N, n, wg):
     packed = np.zeros((nodes.size, n), dtype=np.uint32)
     lib().orc_sample_neighbors(seeds, nodes, nodes.size, N, n, wg, table.reshape(-1), packed.reshape(-1))
     return table, packed
+
+
+def _bind_samplers(L):
+    L.orc_uset_order.restype = C.c_uint64
+    L.orc_uset_order.argtypes = [u64p, C.c_uint64, u64p]
+    L.orc_host_sample.restype = C.c_int
+    L.orc_host_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint), u64p, C.c_uint64,
+                                  u64p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
+                                  u64p, C.c_uint64, C.POINTER(C.c_uint64), u32p, C.c_uint64, C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_float)]
+    return L
+
+
+def uset_order(keys):
+    """Iteration order of libstdc++'s std::unordered_set<uint64_t> after inserting `keys` in order (restated)."""
+    L = _bind_samplers(lib())
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    out = np.zeros(max(keys.size, 1), dtype=np.uint64)
+    n = L.orc_uset_order(keys, keys.size, out)
+    return out[:n].copy()
+
+
+STRATEGIES = {"Node": 0, "NodeLink": 1, "NodeNonLink": 2, "BFLink": 3, "BFNonLink": 4, "BF": 5}
+
+
+def host_sample(N, E, mini_batch, strategy, seed, training_edges, tset, hset, edges_cap, nodes_cap):
+    """DoSample's host half (sample.cc:177-303 + learner.cc:162-173) restated: (edges, nodes, weight, seed')."""
+    L = _bind_samplers(lib())
+    te = np.ascontiguousarray(training_edges, dtype=np.uint64)
+    e = np.zeros(max(edges_cap, 1), dtype=np.uint64)
+    v = np.zeros(max(nodes_cap, 1), dtype=np.uint32)
+    ne, nv, w, s = C.c_uint64(), C.c_uint64(), C.c_float(), C.c_uint(seed)
+    ho = hset.slots.ctypes.data if hset is not None else None
+    rc = L.orc_host_sample(N, E, mini_batch, STRATEGIES[strategy], C.byref(s), te, te.size, tset.slots, tset.num_bins,
+                           tset.prime_idx, ho, hset.num_bins if hset is not None else 0,
+                           hset.prime_idx if hset is not None else 0, e, edges_cap, C.byref(ne), v, nodes_cap,
+                           C.byref(nv), C.byref(w))
+    if rc != 0:
+        raise RuntimeError("orc_host_sample rc=%d (needs %d edges, %d nodes)" % (rc, ne.value, nv.value))
+    return e[:ne.value].copy(), v[:nv.value].copy(), float(w.value), int(s.value)

@@ -1,0 +1,89 @@
+"""a9 (host mini-batch samplers): oracle/ammsb_oracle_samplers.c -- a plain-C restatement of sample.cc:177-303 and
+learner.cc:162-173, including the libstdc++ unordered_set iteration order they depend on -- against (1) the real
+container and (2) the product's host samplers (libammsb_host.so), bit for bit, for seeds 1..4 and all six
+strategies ("host sampler outputs (edges, weight, node order) for seeds 1..4")."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def real(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("uset") / "libuset.so")
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "cpp", "uset_order.cc")])
+    L = C.CDLL(so)
+    L.real_uset_order_u64.restype = C.c_uint64
+    L.real_uset_order_u64.argtypes = [np.ctypeslib.ndpointer(np.uint64), C.c_uint64, np.ctypeslib.ndpointer(np.uint64)]
+    L.real_uset_order_u32.restype = C.c_uint64
+    L.real_uset_order_u32.argtypes = [np.ctypeslib.ndpointer(np.uint32), C.c_uint64, np.ctypeslib.ndpointer(np.uint32)]
+    return L
+
+
+def test_unordered_set_order_matches_libstdcxx(orc, real):
+    rng = np.random.default_rng(7)
+    cases = [np.arange(0, dtype=np.uint64), np.array([5], dtype=np.uint64), np.arange(1, 14, dtype=np.uint64)]
+    for n in (2, 11, 12, 13, 14, 29, 30, 97, 98, 1000, 5087, 65536, 200003):   # around every early rehash
+        cases.append(rng.integers(0, 2**20, n, dtype=np.uint64))                 # vertex-like keys, duplicates
+        cases.append((rng.integers(0, 2**20, n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 2**20, n, dtype=np.uint64))
+    cases.append(np.repeat(rng.integers(0, 50, 400, dtype=np.uint64), 3))
+    for keys in cases:
+        keys = np.ascontiguousarray(keys)
+        want = np.zeros(max(keys.size, 1), dtype=np.uint64)
+        n = real.real_uset_order_u64(keys, keys.size, want)
+        got = orc.uset_order(keys)
+        assert got.size == n and np.array_equal(got, want[:n]), keys.size
+        if keys.size and keys.max() < 2**32:   # std::unordered_set<Vertex>: same hash values, same order
+            k32 = keys.astype(np.uint32)
+            w32 = np.zeros(max(k32.size, 1), dtype=np.uint32)
+            n32 = real.real_uset_order_u32(k32, k32.size, w32)
+            assert n32 == n and np.array_equal(w32[:n32].astype(np.uint64), got)
+
+
+class _OSet:
+    def __init__(self, hs):
+        self.slots, self.num_bins, self.prime_idx = hs.Serialize(), hs.BinsPerBucket(), hs.PrimeIdx()
+
+
+@pytest.fixture(scope="module")
+def dataset():
+    import __graft_entry__ as ge
+    ge.build()
+    from mcmc_ammsb_gpu_amd import hostlib
+    N = 3000
+    edges = hostlib.generate_graph(N, 8, 12, seed=5)
+    return hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=3)
+
+
+@pytest.mark.parametrize("strategy", ["Node", "NodeLink", "NodeNonLink", "BFLink", "BFNonLink", "BF"])
+def test_host_samplers_match_the_oracle(orc, dataset, strategy):
+    ds = dataset
+    m = 256
+    tset, hset = _OSet(ds.training), _OSet(ds.heldout)
+    for seed0 in (1, 2, 3, 4):
+        a, b = seed0, seed0
+        for it in range(6):   # the seed stream carries over from one mini-batch to the next (Sample::seed)
+            e1, v1, w1, a = ds.sample(m, strategy, a)
+            e2, v2, w2, b = orc.host_sample(ds.N, ds.E, m, strategy, b, ds.training_edges, tset, hset,
+                                            ds.max_edges(m), ds.max_nodes(m))
+            assert a == b, "rand_r stream diverged"
+            assert np.array_equal(e1, e2), "edge order"
+            assert np.array_equal(v1, v2), "node order"
+            assert np.float32(w1).tobytes() == np.float32(w2).tobytes(), "weight"
+
+
+def test_host_sample_reports_overflow_instead_of_writing(dataset):
+    """the C entry point takes the capacities and refuses a mini-batch that does not fit."""
+    from mcmc_ammsb_gpu_amd import hostlib
+    ds = dataset
+    e = np.zeros(8, dtype=np.uint64)
+    v = np.zeros(8, dtype=np.uint32)
+    ne, nv, w, s = C.c_uint64(), C.c_uint64(), C.c_float(), C.c_uint(1)
+    rc = ds.lib.ammsb_host_sample(ds._h, ds.N, ds.E, 256, hostlib.STRATEGIES["NodeNonLink"], C.byref(s), e, e.size,
+                                  C.byref(ne), v, v.size, C.byref(nv), C.byref(w))
+    assert rc == -2 and ne.value == 256 and nv.value >= 256
+    assert not e.any() and not v.any()   # nothing was copied
