@@ -55,6 +55,12 @@ int ammsb_host_dataset_training_csr(const ammsb_host_dataset* d, uint64_t* offse
  * eta1) from std::mt19937(6342455113) */
 int ammsb_host_theta_init(uint64_t K, float eta0, float eta1, float* theta_out);
 
+/* MakeEdgesForTrainingPerplexity (learner.cc:47-75): the first ratio * |training| training edges followed by
+ * links * (N(N-1)/2) / E sampled non-links (rand_r stream from `seed`).  *out is malloc'd (ammsb_host_free).
+ * Returns the number of edges or -1 (too many for one launch / bad arguments). */
+int64_t ammsb_host_train_ppx_edges(const ammsb_host_dataset* d, uint64_t N, uint64_t E, float ratio, unsigned seed,
+                                   uint64_t** out);
+
 /* host mini-batch sampling (sample.cc:177-303 + learner.cc:162-173).  strategy: 0 Node, 1 NodeLink,
  * 2 NodeNonLink, 3 BFLink, 4 BFNonLink, 5 BF.  *seed is the rand_r state (Sample::seed).  edges_out
  * must hold max(mini_batch, max_fan_out) keys, nodes_out max(2*mini_batch, 1+max_fan_out) ids.

@@ -53,6 +53,13 @@ struct Config {
 
   bool phi_disable_noise;
 
+  // MCMC_CALC_TRAIN_PPX (CMakeLists.txt:41, config.h:26-28,71-73, learner.cc:47-75) as a run-time switch instead of
+  // a build option: a second PerplexityCalculator over a subset of the training edges plus sampled non-links.
+  bool calc_train_ppx;        // default false = the reference's build default (OFF)
+  Float training_ppx_ratio;   // subset of training edges used for training ppx (default 0.01)
+  unsigned int training_ppx_seed;  // new: rand_r seed of the sampled non-links (the reference draws them from the
+                                   // process-global rand(), which the HIP runtime's start-up also consumes)
+
   SampleStrategy strategy;
 
   // Accepted for source compatibility.  All four values select the register-resident work-group

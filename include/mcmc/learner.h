@@ -24,6 +24,7 @@ class Learner {
 
   void Run(uint32_t max_iters, sig_atomic_t* signaled = nullptr);  // learner.cc:214-250
   Float HeldoutPerplexity();                                       // learner.cc:196-203
+  Float TrainingPerplexity();                                      // learner.cc:204-212 (Config::calc_train_ppx)
   void PrintStats(std::ostream& out);                              // learner.cc:252-299
   void PrintStats();
   bool Serialize(std::ostream* out);  // learner.cc:301-330
@@ -60,6 +61,10 @@ class Learner {
   std::unique_ptr<OpenClSet> trainingSet_;
   std::unique_ptr<OpenClSet> heldoutSet_;
   clcuda::Buffer<Edge> heldoutEdges_;
+  // Config::calc_train_ppx (the reference's MCMC_CALC_TRAIN_PPX members, learner.h:65-69)
+  std::vector<Edge> trainingPerplexityEdges_;
+  std::unique_ptr<clcuda::Buffer<Edge>> devTrainingPerplexityEdges_;
+  std::unique_ptr<PerplexityCalculator> trainingPerplexity_;
   PerplexityCalculator heldoutPerplexity_;
   PhiUpdater phiUpdater_;
   BetaUpdater betaUpdater_;
@@ -93,6 +98,10 @@ class Learner {
   std::future<Float> futures_[2];
   int phase_;
 };
+
+// learner.cc:47-75: the first training_ppx_ratio * |training| training edges, then links * (N(N-1)/2) / E random
+// pairs (u != v, MakeEdge(u, v) as drawn -- NOT canonicalised, as in the reference) that are in neither set.
+std::vector<Edge> MakeEdgesForTrainingPerplexity(const Config& cfg);
 
 }  // namespace mcmc
 

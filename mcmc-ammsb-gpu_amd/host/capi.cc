@@ -11,6 +11,7 @@
 
 #include "mcmc/config.h"
 #include "mcmc/data.h"
+#include "mcmc/learner.h"
 #include "mcmc/sample.h"
 
 struct ammsb_host_set {
@@ -133,6 +134,25 @@ int ammsb_host_theta_init(uint64_t K, float eta0, float eta1, float* theta_out) 
   auto gamma = std::bind(dist, engine);
   std::generate(theta_out, theta_out + 2 * K, gamma);
   return 0;
+}
+
+int64_t ammsb_host_train_ppx_edges(const ammsb_host_dataset* d, uint64_t N, uint64_t E, float ratio, unsigned seed,
+                                   uint64_t** out) {
+  if (!d || !out || N < 2 || E == 0) return -1;
+  mcmc::Config& cfg = const_cast<mcmc::Config&>(d->cfg);
+  cfg.N = N;
+  cfg.E = E;
+  cfg.training_ppx_ratio = ratio;
+  cfg.training_ppx_seed = seed;
+  try {
+    const std::vector<mcmc::Edge> e = mcmc::MakeEdgesForTrainingPerplexity(cfg);
+    *out = static_cast<uint64_t*>(malloc(sizeof(uint64_t) * (e.empty() ? 1 : e.size())));
+    if (!*out) return -1;
+    memcpy(*out, e.data(), sizeof(uint64_t) * e.size());
+    return static_cast<int64_t>(e.size());
+  } catch (const std::exception&) {
+    return -1;
+  }
 }
 
 int ammsb_host_sample(const ammsb_host_dataset* d, uint64_t N, uint64_t E, uint64_t mini_batch, int strategy,

@@ -43,6 +43,9 @@ Config::Config() {  // config.h:69-101
   sum_grads_vector_width = 1;
   device_sampling = false;
   async_launch = false;
+  calc_train_ppx = false;
+  training_ppx_ratio = 0.01;  // config.h:72
+  training_ppx_seed = 1;
   graph_launch = false;
   device_sampling_seed = {1234, 5678};
   device_sampling_host_seed = 20260101;

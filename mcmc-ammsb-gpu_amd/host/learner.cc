@@ -28,6 +28,32 @@ clcuda::Buffer<Edge> Upload(const clcuda::Queue& q, const std::vector<Edge>& v) 
 }
 }  // namespace
 
+std::vector<Edge> MakeEdgesForTrainingPerplexity(const Config& cfg) {
+  const uint64_t total = (cfg.N * (cfg.N - 1)) / 2;
+  const uint64_t num_links = static_cast<uint64_t>(cfg.training_ppx_ratio * cfg.training_edges.size());
+  const uint64_t num_non_links = static_cast<uint64_t>(num_links * total / static_cast<double>(cfg.E));
+  if (num_links + num_non_links >= (1ull << 31))
+    throw std::runtime_error("training perplexity: " + std::to_string(num_links + num_non_links) +
+                             " edges (links * N(N-1)/2 / E non-links, learner.cc:50-53) do not fit one launch; lower "
+                             "training_ppx_ratio");
+  std::vector<Edge> ret(num_links + num_non_links);
+  std::copy(cfg.training_edges.begin(), cfg.training_edges.begin() + num_links, ret.begin());
+  unsigned int seed = cfg.training_ppx_seed;
+  for (uint64_t i = num_links; i < ret.size(); ++i) {
+    Vertex u, v;
+    Edge e;
+    do {
+      u = static_cast<Vertex>(rand_r(&seed) % cfg.N);
+      do {
+        v = static_cast<Vertex>(rand_r(&seed) % cfg.N);
+      } while (u == v);
+      e = MakeEdge(u, v);
+    } while (cfg.training->Has(e) || (cfg.heldout && cfg.heldout->Has(e)));
+    ret[i] = e;
+  }
+  return ret;
+}
+
 Learner::Learner(const Config& cfg, clcuda::Queue queue)
     : cfg_(cfg),
       queue_(queue),
@@ -51,6 +77,14 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
       edges_done_(0),
       phase_(0) {
   if (!sampler_) throw std::runtime_error("Unkown sample strategy");  // learner.cc:146
+  if (cfg_.calc_train_ppx) {  // learner.cc:92-104
+    trainingPerplexityEdges_ = MakeEdgesForTrainingPerplexity(cfg_);
+    if (trainingPerplexityEdges_.empty()) throw std::runtime_error("training perplexity: no edges (raise training_ppx_ratio)");
+    devTrainingPerplexityEdges_.reset(new clcuda::Buffer<Edge>(queue_.GetContext(), queue_, trainingPerplexityEdges_.begin(),
+                                                               trainingPerplexityEdges_.end()));
+    trainingPerplexity_.reset(new PerplexityCalculator(PerplexityCalculator::EDGE_PER_WORKGROUP, cfg_, queue_, beta_,
+                                                       pi_.get(), *devTrainingPerplexityEdges_, trainingSet_.get()));
+  }
   samples_[0].reset(new Sample(cfg_, queue_, cfg_.sample_seed[0]));
   samples_[1].reset(new Sample(cfg_, queue_, cfg_.sample_seed[1]));
   if (cfg_.device_sampling) {
@@ -273,6 +307,14 @@ Float Learner::DoSample(Sample* sample) {
   return weight;
 }
 
+Float Learner::TrainingPerplexity() {  // learner.cc:204-212
+  if (!trainingPerplexity_) throw std::runtime_error("TrainingPerplexity() needs Config::calc_train_ppx");
+  const auto t1 = high_resolution_clock::now();
+  const Float ppx = (*trainingPerplexity_)();
+  time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
+  return std::exp(ppx);
+}
+
 Float Learner::HeldoutPerplexity() {
   const auto t1 = high_resolution_clock::now();
   const Float ppx = heldoutPerplexity_();
@@ -424,7 +466,9 @@ bool Learner::Serialize(std::ostream* out) {
   queue_.Finish();
   return ::mcmc::Serialize(out, &beta_, &queue_) && ::mcmc::Serialize(out, &theta_, &queue_) &&
          ::mcmc::Serialize(out, pi_.get(), &queue_) && ::mcmc::Serialize(out, &phi_, &queue_) &&
-         phiUpdater_.Serialize(out) && betaUpdater_.Serialize(out) && heldoutPerplexity_.Serialize(out) &&
+         phiUpdater_.Serialize(out) && betaUpdater_.Serialize(out) &&
+         (!trainingPerplexity_ || trainingPerplexity_->Serialize(out)) &&  // learner.cc:321-323
+         heldoutPerplexity_.Serialize(out) &&
          SerializeMessage(out, props) && samples_[0]->Serialize(out) && samples_[1]->Serialize(out) &&
          SerializeDeviceSampler(out);
 }
@@ -460,7 +504,8 @@ bool Learner::Parse(std::istream* in) {
   LearnerProperties props;
   if (!(::mcmc::Parse(in, &beta_, &queue_) && ::mcmc::Parse(in, &theta_, &queue_) &&
         ::mcmc::Parse(in, pi_.get(), &queue_) && ::mcmc::Parse(in, &phi_, &queue_) && phiUpdater_.Parse(in) &&
-        betaUpdater_.Parse(in) && heldoutPerplexity_.Parse(in) && ParseMessage(in, &props)))
+        betaUpdater_.Parse(in) && (!trainingPerplexity_ || trainingPerplexity_->Parse(in)) &&  // learner.cc:339-341
+        heldoutPerplexity_.Parse(in) && ParseMessage(in, &props)))
     return false;
   stepCount_ = props.stepCount;
   time_ = props.time;
@@ -491,6 +536,10 @@ void Learner::PrintStats(std::ostream& out) {  // learner.cc:252-299: same categ
   out << "TOTAL    : " << total << "\n";
   line("PPX CALC ", heldoutPerplexity_.PerplexityTime());
   line("PPX ACCUM", heldoutPerplexity_.AccumulateTime());
+  if (trainingPerplexity_) {  // learner.cc:262-271
+    line("TRAIN PPX CALC ", trainingPerplexity_->PerplexityTime());
+    line("TRAIN PPX ACCUM", trainingPerplexity_->AccumulateTime());
+  }
   line("SAMPLING ", samplingTime_);
   line("PHI      ", phiUpdater_.UpdatePhiTime());
   line("PI       ", phiUpdater_.UpdatePiTime());

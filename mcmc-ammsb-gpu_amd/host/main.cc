@@ -79,6 +79,8 @@ int main(int argc, char** argv) {
   cfg.neighbor_seed = {56, 57};
   std::vector<Option> options = {
       OptStr("file", 'f', &filename),
+      Opt("train-ppx-ratio", 0, &cfg.training_ppx_ratio, "0.01"),  // main.cc:47-49 (MCMC_CALC_TRAIN_PPX builds)
+      Opt("train-ppx", 0, &cfg.calc_train_ppx, "0 (new: the reference's MCMC_CALC_TRAIN_PPX build option at run time)"),
       Opt("heldout-ratio", 'r', &cfg.heldout_ratio, "0.01"),
       Opt("alpha", 0, &cfg.alpha, "0"),
       Opt("a", 'a', &cfg.a, "0.0315"),
@@ -201,6 +203,8 @@ int main(int argc, char** argv) {
     const uint64_t step = std::min<uint64_t>(max_iters - i, cfg.ppx_interval);
     learner.Run(static_cast<uint32_t>(step), &signaled);
     if (!signaled) std::cerr << "I ppx[" << i + step << "] = " << learner.HeldoutPerplexity() << std::endl;
+    if (!signaled && cfg.calc_train_ppx)
+      std::cerr << "I train ppx[" << i + step << "] = " << learner.TrainingPerplexity() << std::endl;
   }
   if (signaled) std::cerr << "I FORCED TERMINATE" << std::endl;
   if (!ckptOut.empty()) {

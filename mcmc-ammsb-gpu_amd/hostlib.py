@@ -43,6 +43,7 @@ SIGNATURES = {
     "ammsb_host_dataset_training_csr": (C.c_int, [_vp, _u64p, _u32p]),
     "ammsb_host_theta_init": (C.c_int, [_u64, C.c_float, C.c_float,
                                         np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]),
+    "ammsb_host_train_ppx_edges": (C.c_int64, [_vp, _u64, _u64, C.c_float, C.c_uint, C.POINTER(C.POINTER(C.c_uint64))]),
     "ammsb_host_sample": (C.c_int, [_vp, _u64, _u64, _u64, C.c_int, C.POINTER(C.c_uint), _u64p, _u64,
                                     C.POINTER(_u64), _u32p, _u64, C.POINTER(_u64), C.POINTER(C.c_float)]),
 }
@@ -198,6 +199,14 @@ class Dataset:
         tgt = np.zeros(2 * self.training_edges.size, dtype=np.uint32)
         self.lib.ammsb_host_dataset_training_csr(self._h, off, tgt)
         return off, tgt
+
+    def train_ppx_edges(self, ratio=0.01, seed=1):
+        """MakeEdgesForTrainingPerplexity (learner.cc:47-75)."""
+        p = C.POINTER(C.c_uint64)()
+        n = self.lib.ammsb_host_train_ppx_edges(self._h, self.N, self.E, ratio, seed, C.byref(p))
+        if n < 0:
+            raise AmmsbError("training perplexity edge list: too many edges for one launch (lower the ratio)")
+        return _take(p, n)
 
     def max_nodes(self, mini_batch):
         return max(2 * mini_batch, 1 + self.max_fan_out)  # phi.cc:620-622

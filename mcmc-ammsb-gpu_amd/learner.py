@@ -58,6 +58,10 @@ class Config:
         self.beta_seed = (113, 117)
         self.neighbor_seed = (3337, 54351)
         self.phi_disable_noise = False
+        # MCMC_CALC_TRAIN_PPX (CMakeLists.txt:41, config.h:26-28, learner.cc:47-75) as a run-time switch
+        self.calc_train_ppx = False
+        self.training_ppx_ratio = 0.01
+        self.training_ppx_seed = 1                   # (new) rand_r seed of the sampled non-links
         self.strategy = "Node"
         # kernel-variant knobs of the reference (config.h:60-66): accepted for source compatibility; every value
         # selects this build's one kernel family
@@ -152,6 +156,14 @@ class Learner:
         # learner.cc:105-116
         self.heldoutPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.heldoutEdges,
                                                           self.heldoutSet, cfg.ppx_wg_size)
+        self.trainingPerplexity = None
+        if cfg.calc_train_ppx:  # learner.cc:92-104
+            te = dataset.train_ppx_edges(cfg.training_ppx_ratio, cfg.training_ppx_seed)
+            if te.size == 0:
+                raise AmmsbError("training perplexity: no edges (raise training_ppx_ratio)")
+            self.trainingPerplexityEdges = c.from_numpy(te)
+            self.trainingPerplexity = ops.PerplexityCalculator(c, self.beta, self.pi, self.trainingPerplexityEdges,
+                                                               self.trainingSet, cfg.ppx_wg_size)
         self.phiUpdater = ops.PhiUpdater(c, self.beta, self.pi, self.phi, self.trainingSet, phi_rows,
                                          cfg.phi_seed, cfg.phi_wg_size, cfg.phi_disable_noise)
         self.betaUpdater = ops.BetaUpdater(c, self.theta, self.beta, self.pi, self.trainingSet, cfg.beta_seed,
@@ -480,9 +492,17 @@ class Learner:
             self.stepCount += 1
         self.time += time.perf_counter() - t1
 
+    def TrainingPerplexity(self):
+        """learner.cc:204-212 (Config.calc_train_ppx)."""
+        if self.trainingPerplexity is None:
+            raise AmmsbError("TrainingPerplexity() needs Config.calc_train_ppx")
+        return self._perplexity(self.trainingPerplexity)
+
     def HeldoutPerplexity(self):
+        return self._perplexity(self.heldoutPerplexity)
+
+    def _perplexity(self, calc):
         t1 = time.perf_counter()
-        calc = self.heldoutPerplexity
         calc.count_calls += 1
         H = calc.num_edges
         per = (H + self.world - 1) // self.world
@@ -546,13 +566,13 @@ class Learner:
                 break
             rows = seeds[lo * L:min(hi * L, seeds.shape[0])]
             ops.wait_work(ops.broadcast_async(dist, rows, b % R, self.group))
-        calc = self.heldoutPerplexity
-        H = calc.num_edges
-        per = (H + R - 1) // R
-        for r in range(R):
-            lo, hi = min(r * per, H), min((r + 1) * per, H)
-            if lo < hi:
-                ops.wait_work(ops.broadcast_async(dist, calc.ppx_per_edge[lo:hi], r, self.group))
+        for calc in ([self.trainingPerplexity] if self.trainingPerplexity is not None else []) + [self.heldoutPerplexity]:
+            H = calc.num_edges
+            per = (H + R - 1) // R
+            for r in range(R):
+                lo, hi = min(r * per, H), min((r + 1) * per, H)
+                if lo < hi:
+                    ops.wait_work(ops.broadcast_async(dist, calc.ppx_per_edge[lo:hi], r, self.group))
         ops.synchronize()
 
     def Serialize(self, out):
@@ -581,10 +601,10 @@ class Learner:
         ck.write_buffer(out, self.betaUpdater.rand.seeds)
         ck.write_buffer(out, self._theta_sum())  # derived: recomputed by every beta_grads launch
         ck.write_message(out, [(1, ck.VARINT, self.betaUpdater.count_calls)] + [(i, ck.FIXED64, 0.0) for i in range(2, 7)])
-        # PerplexityCalculatorBase::Serialize (perplexity.cc:276-283)
-        calc = self.heldoutPerplexity
-        ck.write_message(out, [(1, ck.VARINT, calc.count_calls), (2, ck.FIXED64, 0.0), (3, ck.FIXED64, 0.0)])
-        ck.write_buffer(out, calc.ppx_per_edge)
+        # PerplexityCalculatorBase::Serialize (perplexity.cc:276-283); the training calculator first (learner.cc:321-324)
+        for calc in ([self.trainingPerplexity] if self.trainingPerplexity is not None else []) + [self.heldoutPerplexity]:
+            ck.write_message(out, [(1, ck.VARINT, calc.count_calls), (2, ck.FIXED64, 0.0), (3, ck.FIXED64, 0.0)])
+            ck.write_buffer(out, calc.ppx_per_edge)
         ck.write_message(out, [(1, ck.VARINT, self.stepCount), (2, ck.VARINT, int(self.time * 1e9)),
                                (3, ck.VARINT, int(self.samplingTime * 1e9)), (4, ck.VARINT, self.phase),
                                (5, ck.FIXED64, weight)])
@@ -616,9 +636,9 @@ class Learner:
         ck.read_buffer(inp, self.betaUpdater.rand.seeds)
         ck.read_buffer(inp, self._theta_sum())  # size check only
         self.betaUpdater.count_calls = int(ck.read_message(inp, (1, 2, 3, 4, 5, 6))[1])
-        calc = self.heldoutPerplexity
-        calc.count_calls = int(ck.read_message(inp, (1, 2, 3))[1])
-        ck.read_buffer(inp, calc.ppx_per_edge)
+        for calc in ([self.trainingPerplexity] if self.trainingPerplexity is not None else []) + [self.heldoutPerplexity]:
+            calc.count_calls = int(ck.read_message(inp, (1, 2, 3))[1])
+            ck.read_buffer(inp, calc.ppx_per_edge)
         props = ck.read_message(inp, (1, 2, 3, 4, 5))
         self.stepCount = int(props[1])
         self.time, self.samplingTime = props[2] * 1e-9, props[3] * 1e-9

@@ -186,3 +186,52 @@ def test_serialize_end_to_end_reference_shape(env, device_sampling):
     l2.Run(iters)
     assert l2.HeldoutPerplexity() == ppx
     l2.close()
+
+
+def test_training_perplexity_mode(env, orc):
+    """MCMC_CALC_TRAIN_PPX (learner.cc:47-75, :204-212, :321-323) as Config.calc_train_ppx: the edge list follows the
+    reference's construction, the value matches the oracle over that list, and the checkpoint carries the extra
+    PerplexityCalculator record between BetaUpdater's and the held-out calculator's."""
+    ops, hostlib, learner, torch = env
+    N = 2000
+    edges = hostlib.generate_graph(N, 8, 12, seed=3)
+    ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=3)
+    ratio = 0.05
+    te = ds.train_ppx_edges(ratio, 1)
+    links = int(np.float32(ratio) * ds.training_edges.size)
+    non = int(links * ((N * (N - 1)) // 2) / float(ds.E))
+    assert te.size == links + non and np.array_equal(te[:links], ds.training_edges[:links])
+    rest = te[links:]
+    assert ((rest >> np.uint64(32)) != (rest & np.uint64(0xFFFFFFFF))).all()
+    assert not ds.training.Has(rest).any() and not ds.heldout.Has(rest).any()
+
+    def cfg():
+        return learner.Config.from_cli_defaults(K=64, mini_batch_size=128, num_node_sample=8, phi_wg_size=64,
+                                                beta_wg_size=64, ppx_wg_size=64, calc_train_ppx=True,
+                                                training_ppx_ratio=ratio)
+    l1 = learner.Learner(cfg(), ds)
+    got = l1.TrainingPerplexity()
+    po = orc.make_params(N, 64, 8)
+    state = np.zeros(te.size, dtype=np.float32)
+    sums, _ = orc.perplexity(po, ops.to_numpy(l1.beta), l1.pi.host().reshape(-1), _OSet(ds.training), te, 1, 64, 1, state)
+    want = float(np.exp(np.float32(-(sums.link_ll + sums.nonlink_ll) / (sums.link_cnt + sums.nonlink_cnt))))
+    assert sums.link_cnt == links and sums.nonlink_cnt == non
+    assert abs(got - want) <= TIGHT * want
+    assert np.array_equal(ops.to_numpy(l1.trainingPerplexity.ppx_per_edge), state)
+    l1.Run(15)
+    out = io.BytesIO()
+    assert l1.Serialize(out)
+    l1.Run(15)
+    a = (l1.TrainingPerplexity(), l1.HeldoutPerplexity())
+    l1.close()
+    l2 = learner.Learner(cfg(), ds)
+    assert l2.Parse(io.BytesIO(out.getvalue()))
+    l2.Run(15)
+    assert (l2.TrainingPerplexity(), l2.HeldoutPerplexity()) == a
+    l2.close()
+    # a learner without the mode refuses the call and reads a stream without the record
+    plain = learner.Learner(learner.Config.from_cli_defaults(K=64, mini_batch_size=128, num_node_sample=8, phi_wg_size=64,
+                                                             beta_wg_size=64, ppx_wg_size=64), ds)
+    with pytest.raises(ops.AmmsbError):
+        plain.TrainingPerplexity()
+    plain.close()
