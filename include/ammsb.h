@@ -106,6 +106,17 @@ int ammsb_rng_init_mixed(ammsb_ctx* ctx, ammsb_seed* seeds, uint64_t n, uint64_t
 int ammsb_set_has(ammsb_ctx* ctx, const ammsb_set* set, const uint64_t* keys, uint64_t n, uint8_t* out,
                   void* stream);
 
+/* ---- parallel set construction on the device (new, opt-in; the reference inserts on one host thread with a rand_r
+ *      random walk, cuckoo.cc:117-161 -- that image is what parity runs use and host/cuckoo.cc reproduces it) ----
+ * Builds a VALID table of the same layout and hash pairs from n device-resident keys (distinct, != UINT64_MAX):
+ * membership is exactly the key set; WHICH slot holds a key depends on the interleaving, so the image differs from
+ * the host build's.  num_bins >= ammsb_set_num_bins(n) = 1 + ceil(1.15 n / 8); slots: [2 * num_bins * 4] u64;
+ * scratch: one u32.  Tries the four hash pairs in turn like Set::SetContents (cuckoo.cc:117-129) and reports the
+ * one that worked; AMMSB_ERANGE if none did.  Synchronises the stream (it needs the outcome of each attempt). */
+uint64_t ammsb_set_num_bins(uint64_t n);
+int ammsb_set_build(ammsb_ctx* ctx, const uint64_t* keys, uint64_t n, uint64_t* slots, uint64_t num_bins,
+                    uint32_t* prime_idx_out, uint32_t* scratch, void* stream);
+
 /* random::RandomGammaAndNormalize, random.cc:159-167: pi rows ~ Gamma(eta0, eta1) from N*32 streams
  * (caller initialises them with {11,113}), then row-normalise; phi_sum[row] = row sum. */
 int ammsb_pi_init_gamma(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, float eta0, float eta1,

@@ -74,6 +74,8 @@ SIGNATURES = {
     "ammsb_rng_init": [_vp, _vp, _u64, _u64, _u64, _vp],
     "ammsb_rng_init_mixed": [_vp, _vp, _u64, _u64, _u64, _vp],
     "ammsb_set_has": [_vp, _P(SetDesc), _vp, _u64, _vp, _vp],
+    "ammsb_set_num_bins": [_u64],
+    "ammsb_set_build": [_vp, _vp, _u64, _vp, _u64, _P(_u32), _vp, _vp],
     "ammsb_pi_init_gamma": [_vp, _P(Rpm), _vp, _f32, _f32, _vp, _vp],
     "ammsb_sample_neighbors": [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "ammsb_update_phi": [_vp, _vp, _P(Rpm), _vp, _P(SetDesc), _vp, _vp, _u32, _u32, _vp, _u32, _u32,
@@ -104,7 +106,7 @@ SIGNATURES = {
 }
 _OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_eps_t": C.c_float,
               "ammsb_minibatch_candidates": C.c_uint32, "ammsb_minibatch_candidates_for": C.c_uint32,
-              "ammsb_minibatch_workspace_bytes": C.c_uint64}
+              "ammsb_minibatch_workspace_bytes": C.c_uint64, "ammsb_set_num_bins": C.c_uint64}
 
 _lib = None
 

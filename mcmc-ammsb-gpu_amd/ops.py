@@ -184,6 +184,25 @@ class DeviceSet:
         self.prime_idx = int(prime_idx)
         self.desc = SetDesc(self.data.data_ptr(), self.num_bins, self.prime_idx)
 
+    @classmethod
+    def build_on_device(cls, ctx, keys):
+        """Opt-in parallel construction on the GPU (ammsb_set_build): same layout and hash pairs, exact membership,
+        a different (interleaving-dependent) image than the host's rand_r random-walk build, which stays the
+        default and is what parity runs use.  `keys`: distinct u64 keys, a device tensor or a host array."""
+        k = keys if torch.is_tensor(keys) else ctx.from_numpy(np.ascontiguousarray(keys, dtype=np.uint64))
+        n = int(k.numel())
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.num_bins = int(ctx.lib.ammsb_set_num_bins(n))
+        self.data = ctx.empty((2 * self.num_bins * 4,), torch.int64)
+        scratch = ctx.zeros((1,), torch.int32)
+        pidx = C.c_uint32(0)
+        ctx.check(ctx.lib.ammsb_set_build(ctx.handle, _ptr(k), n, _ptr(self.data), self.num_bins, C.byref(pidx),
+                                          _ptr(scratch), _stream()))
+        self.prime_idx = int(pidx.value)
+        self.desc = SetDesc(self.data.data_ptr(), self.num_bins, self.prime_idx)
+        return self
+
     def Has(self, keys):
         """The `find` kernel of cuckoo-test.cc:45-53 over a device or host key array."""
         k = keys if torch.is_tensor(keys) else self.ctx.from_numpy(np.asarray(keys, dtype=np.uint64))

@@ -347,4 +347,20 @@ def test_c5_full_size(env, orc):
     r0, r1, k0, k1 = calc.unpack(calc.partial(lo, lo + 256))
     assert (k0, k1) == (osums.link_cnt, osums.nonlink_cnt) == (int(member.sum()), 256 - int(member.sum()))
     assert abs(r0 - osums.link_ll) <= 1e-10 * abs(osums.link_ll) and abs(r1 - osums.nonlink_ll) <= 1e-10 * abs(osums.nonlink_ll)
+    # ---- the 3.2e8 training keys built into a table ON THE DEVICE (opt-in; the host build above took
+    # most of this test's set-up time): exact membership on samples of members and of held-out / fake pairs
+    import time
+    keys_dev = ctx.from_numpy(ds.training_edges)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dset2 = ops.DeviceSet.build_on_device(ctx, keys_dev)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    print("device cuckoo build of %d keys: %.2f s (prime pair %d)" % (ds.training_edges.size, build_s, dset2.prime_idx))
+    assert dset2.num_bins == ds.training.BinsPerBucket()
+    sample = ds.training_edges[rng.integers(0, ds.training_edges.size, 2_000_000)]
+    assert bool(dset2.Has(sample).all())
+    assert np.array_equal(dset2.Has(ds.heldout_edges).cpu().numpy().astype(bool), ds.training.Has(ds.heldout_edges))
+    assert int((dset2.data != -1).sum()) == ds.training_edges.size      # each key once, nothing else
+    del dset2, keys_dev
     lrn.close()
