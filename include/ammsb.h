@@ -136,6 +136,11 @@ int ammsb_update_phi(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, con
                      uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
                      uint32_t group_begin, uint32_t group_end, float* phi_vec, void* stream);
 
+/* Diagnostic: blocks of the LDS-streamed update_phi kernel that fit one CU for this context's (K, n) and `wg`
+ * (registers + LDS, from the runtime's occupancy calculator), and the waves per block.  0 blocks = the register
+ * kernel is used for that shape. */
+int ammsb_update_phi_occupancy(ammsb_ctx* ctx, uint32_t wg, int* blocks_per_cu, int* waves_per_block);
+
 /* PhiUpdater::operator() second half, phi.cc:758-762, kernel update_pi (phi.cc:177-197):
  * pi[nodes[i], :] = phi_vec[i, :] / sum, phi_sum[nodes[i]] = sum (WG_SUM order for `wg`). */
 int ammsb_update_pi(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
@@ -182,7 +187,7 @@ int ammsb_minibatch_link(ammsb_ctx* ctx, const uint64_t* csr_offsets, const uint
 /* number of candidate draws (= RNG streams, = workspace entries) ammsb_minibatch_nonlink needs for
  * m distinct non-links out of N vertices when up to `excluded` vertices are invalid partners of u (u itself and
  * its neighbours in the training and held-out graphs): enough draws for m + excluded distinct values plus a
- * margin of 8 % + 1024.  0 if N is too small (needs N >= 2m and the target below 0.95 N).  Size the streams
+ * margin of 8 % + min(1024, N / 8).  0 if N is too small (needs N >= 2m and the target below 0.95 N).  Size the streams
  * and the workspace for the largest `excluded` of the graph (capacity), and pass the per-vertex value
  * (<= capacity) to each call.  ammsb_minibatch_candidates(N, m) = ..._for(N, m, 0). */
 uint32_t ammsb_minibatch_candidates(uint64_t N, uint32_t m);

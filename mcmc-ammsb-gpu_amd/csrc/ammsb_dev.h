@@ -19,15 +19,24 @@ namespace ammsb {
 
 #include "zig_tables.inc"  // zig_ytab / zig_wtab / zig_ktab (tools/gen_ziggurat_tables.py)
 
-struct ZigTables {  // LDS copy, 1.5 KiB per block
+// LDS copy of the ziggurat tables, 1.5 KiB per block.  Only wtab and ktab are read on the fast path; ytab is read
+// by about one draw in 80.  Leaving ytab in global memory (-DAMMSB_ZIG_YTAB_GLOBAL: 1 KiB of LDS) lets twelve
+// instead of eleven one-wave blocks of the K = 1024 phi kernel share a CU (ammsb_update_phi_occupancy reports 12 vs
+// 11), but every slow-path draw then stalls its whole wave on a global load: measured 3-9 % SLOWER per launch in
+// three alternating same-box pairs (1.73 / 1.77 / 1.77 ms against 1.56 / 1.72 / 1.64 ms), so the tables stay in LDS.
+struct ZigTables {
+#ifndef AMMSB_ZIG_YTAB_GLOBAL
   float ytab[128];
+#endif
   float wtab[128];
   uint32_t ktab[128];
 };
 
 __device__ __forceinline__ void zig_load(ZigTables* t) {
   for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+#ifndef AMMSB_ZIG_YTAB_GLOBAL
     t->ytab[i] = zig_ytab[i];
+#endif
     t->wtab[i] = zig_wtab[i];
     t->ktab[i] = zig_ktab[i];
   }
@@ -66,7 +75,11 @@ __device__ __forceinline__ float rng_normal(ammsb_seed& s, const ZigTables* t) {
     x = (float)j * t->wtab[i];
     if (j < t->ktab[i]) break;
     if (i < 127) {
+#ifndef AMMSB_ZIG_YTAB_GLOBAL
       const float y0 = t->ytab[i], y1 = t->ytab[i + 1];
+#else
+      const float y0 = zig_ytab[i], y1 = zig_ytab[i + 1];
+#endif
       const float U1 = rng_uniform(s);
       const float d = y0 - y1;
       const float m = d * U1;

@@ -202,8 +202,9 @@ extern "C" uint32_t ammsb_minibatch_candidates_for(uint64_t N, uint32_t m, uint6
   if (m == 0 || N < 2ull * m) return 0;
   // C draws from N values leave about N (1 - exp(-C/N)) distinct ones.  Up to `excluded` of them can be invalid
   // partners of u (u itself, its training and held-out neighbours), so ask for m + excluded distinct values plus a
-  // margin of 8 % + 1024 against an unlucky draw.
-  const double want = 1.08 * ((double)m + (double)excluded) + 1024.0;
+  // margin of 8 % + 1024 (N / 8 on small graphs) against an unlucky draw.
+  const double slack = (double)N / 8.0 < 1024.0 ? (double)N / 8.0 : 1024.0;
+  const double want = 1.08 * ((double)m + (double)excluded) + slack;
   if (want >= 0.95 * (double)N) return 0;
   const double c = -(double)N * log(1.0 - want / (double)N);
   uint64_t C = (uint64_t)ceil(c) + 256;

@@ -711,6 +711,35 @@ int ammsb_update_phi_d(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, c
                            0xFFFFFFFFu, phi_vec, desc, stamps, stream);
 }
 
+// Diagnostic: resident blocks per CU of the LDS-streamed update_phi kernel picked for (K, wg), as the runtime's
+// occupancy calculator sees it (registers, static + dynamic LDS).  0 if (K, wg) takes the register kernel.
+template <int KPT, int W, int D>
+static int occ_of(uint32_t n, int* out) {
+  const size_t lds = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * n;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, update_phi_lds_kernel<KPT, W, D>, 64 * W, lds) == hipSuccess
+             ? AMMSB_OK
+             : AMMSB_EHIP;
+}
+
+extern "C" int ammsb_update_phi_occupancy(ammsb_ctx* ctx, uint32_t wg, int* blocks_per_cu, int* waves_per_block) {
+  AMMSB_CHECK_ARG(ctx, ctx && blocks_per_cu && waves_per_block, "null argument");
+  const ammsb_params& p = ctx->params;
+  const int kpt = pick_kpt(p.K, wg);
+  const uint32_t n = p.num_node_sample;
+  *blocks_per_cu = 0;
+  *waves_per_block = (int)(wg / 64);
+  if (kpt == 0 || p.K != (uint64_t)wg * kpt) return AMMSB_OK;
+  if (wg == 64 && kpt == 4) return occ_of<4, 1, 8>(n, blocks_per_cu);
+  if (wg == 64 && kpt == 8) return occ_of<8, 1, 4>(n, blocks_per_cu);
+  if (wg == 64 && kpt == 16) return occ_of<16, 1, 2>(n, blocks_per_cu);
+  if (wg == 64 && kpt == 32) return occ_of<32, 1, 2>(n, blocks_per_cu);
+  if (wg == 128 && kpt == 8) return occ_of<8, 2, 2>(n, blocks_per_cu);
+  if (wg == 128 && kpt == 16) return occ_of<16, 2, 2>(n, blocks_per_cu);
+  if (wg == 256 && kpt == 16) return occ_of<16, 4, 2>(n, blocks_per_cu);
+  if (wg == 512 && kpt == 16) return occ_of<16, 8, 2>(n, blocks_per_cu);
+  return AMMSB_OK;
+}
+
 static int update_pi_common(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const float* phi_vec,
                             const uint32_t* nodes, uint32_t n_nodes, uint32_t wg, const ammsb_step_desc* desc,
                             unsigned long long* stamps, void* stream) {

@@ -191,7 +191,7 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
 }
 
 uint32_t Learner::CandidatesForExcluded(uint32_t excluded) {
-  const uint32_t key = (excluded + 255u) / 256u * 256u;  // few distinct values
+  const uint32_t key = (excluded + 31u) / 32u * 32u;  // few distinct values
   auto it = cand_cache_.find(key);
   if (it != cand_cache_.end()) return it->second;
   const uint32_t c = ammsb_minibatch_candidates_for(cfg_.N, static_cast<uint32_t>(cfg_.mini_batch_size), key);

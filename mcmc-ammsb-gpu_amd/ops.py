@@ -480,7 +480,7 @@ class DeviceMiniBatchSampler:
         self._done_valid = False
 
     def _candidates_for(self, excluded):
-        key = (int(excluded) + 255) // 256 * 256  # few distinct values
+        key = (int(excluded) + 31) // 32 * 32  # few distinct values
         c = self._cand.get(key)
         if c is None:
             c = self._cand[key] = int(self.ctx.lib.ammsb_minibatch_candidates_for(self.N, self.m, key))
