@@ -158,6 +158,10 @@ int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, cons
                      const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
                      uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream);
 
+/* Multi-GPU gradient reduction after the all-gather of the R per-rank [cols] vectors into in[R, cols]:
+ * out[c] = in[0][c] + in[1][c] + ... in ascending rank order (a fixed association, identical on every rank). */
+int ammsb_sum_rows_f32(ammsb_ctx* ctx, const float* in, uint32_t rows, uint32_t cols, float* out, void* stream);
+
 /* BetaUpdater::operator() update half, beta.cc:368-383: update_theta (SGLD, stream k for component k,
  * r0 then r1) followed by beta = pair-normalised theta.  seeds: [K]. */
 int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, uint32_t step_count,

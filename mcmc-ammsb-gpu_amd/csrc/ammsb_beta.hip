@@ -751,6 +751,24 @@ int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm
   return AMMSB_OK;
 }
 
+// Multi-GPU: the R per-rank gradient vectors (all-gathered into [R, cols]) are added in rank order, every rank
+// running the same kernel over the same bytes: out[c] = (...((in[0][c] + in[1][c]) + in[2][c]) ...).
+__global__ void sum_rows_kernel(const float* in, uint32_t rows, uint32_t cols, float* out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = in[c];
+  for (uint32_t r = 1; r < rows; ++r) s += in[(uint64_t)r * cols + c];
+  out[c] = s;
+}
+
+extern "C" int ammsb_sum_rows_f32(ammsb_ctx* ctx, const float* in, uint32_t rows, uint32_t cols, float* out,
+                                  void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && in && out && rows > 0 && cols > 0, "bad argument");
+  sum_rows_kernel<<<(cols + 255) / 256, 256, 0, as_stream(stream)>>>(in, rows, cols, out);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 extern "C" int ammsb_theta_sum(ammsb_ctx* ctx, float* out, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && out, "null argument");
   AMMSB_HIP(ctx, hipMemcpyAsync(out, ctx->theta_sum, sizeof(float) * ctx->params.K, hipMemcpyDeviceToDevice,

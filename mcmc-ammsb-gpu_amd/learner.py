@@ -197,6 +197,7 @@ class Learner:
             self.rep_stream = ops.new_stream(c)
             self.ev_fork, self.ev_join = ops.new_event(), ops.new_event()
             self.all_grads = c.zeros((self.world, 2 * K), torch.float32)
+            self.grads_sum = c.zeros((2 * K,), torch.float32)
             self.all_sums = c.zeros((self.world, 4), torch.int64)
             self.tail_buf = c.zeros((max(max_nodes - MAX_GROUPS, 1), K), torch.float32)
         # learner.cc:150-155: theta_0 (host std::gamma) -> beta_0; pi_0 / phi_sum_0 (device gamma {11,113})
@@ -385,8 +386,10 @@ class Learner:
             return local
         dist = self._dist()
         self.ops.all_gather_flat(dist, self.all_grads, local, self.rank, self.world, self.group)
-        # one reduction kernel over the R rows: the association is fixed by the shape, identical on every rank
-        return torch.sum(self.all_grads, dim=0)
+        # one reduction kernel over the R rows in rank order: a fixed association, identical on every rank
+        if hasattr(self.ops, "sum_rows"):
+            return self.ops.sum_rows(self.ctx, self.all_grads, self.grads_sum)
+        return torch.sum(self.all_grads, dim=0)  # CPU stand-in of the tests
 
     # ------------------------------------------------------------------ the loop (learner.cc:214-250)
 
@@ -420,19 +423,23 @@ class Learner:
                     ops.wait_event(o.consumed)
             if s.choice is None:
                 raise AmmsbError("graph_launch: the pending mini-batch was not drawn by the device sampler")
-            nxt = [smp.choose(cfg.strategy) for _ in range(n)]
+            nxt = smp.choose_many(cfg.strategy, n)
             self.loop.run(s.choice, nxt, phi.count_calls + 1, self.phase)
-            consumed = [s.choice] + nxt[:-1]
-            self.edges_done += sum(smp.sizes(ch)[0] for ch in consumed)
+            # mini-batch edges of the n steps just enqueued: the pending choice, then all but the last new one
+            m = cfg.mini_batch_size
+            ne = np.where(nxt["link"][:-1] != 0, nxt["n"][:-1], m).astype(np.int64)
+            first_ne = smp.sizes(s.choice)[0]
+            self.edges_done += int(first_ne + ne.sum())
             if self.step_log is not None:
-                self.step_log.extend(smp.sizes(ch)[:2] for ch in consumed)
+                self.step_log.append((first_ne, first_ne + 1))
+                self.step_log.extend(zip(ne.tolist(), (ne + 1).tolist()))
             phi.count_calls += n
             beta.count_calls += n
             self.stepCount += n
             self.phase ^= n & 1
             # the new pending mini-batch sits in samples[phase]; everything queued so far orders the eager path
             p = self.samples[self.phase]
-            p.choice = nxt[-1]
+            p.choice = tuple(int(x) for x in nxt[-1])
             p.n_edges, p.n_nodes, w = smp.sizes(p.choice)
             f = concurrent.futures.Future()
             f.set_result(w)

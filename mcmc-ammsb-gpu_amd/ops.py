@@ -385,6 +385,13 @@ class BetaUpdater:
         return out
 
 
+def sum_rows(ctx, rows, out):
+    """out[c] = rows[0, c] + rows[1, c] + ... in ascending row order (the multi-GPU gradient reduction)."""
+    ctx.check(ctx.lib.ammsb_sum_rows_f32(ctx.handle, _ptr(rows), int(rows.shape[0]), int(rows.shape[1]), _ptr(out),
+                                         _stream()))
+    return out
+
+
 def beta_from_theta(ctx, theta, beta):
     ctx.check(ctx.lib.ammsb_beta_from_theta(ctx.handle, _ptr(theta), _ptr(beta), _stream()))
 
@@ -426,6 +433,9 @@ class PerplexityCalculator:
     def __call__(self):
         self.count_calls += 1  # perplexity.cc:252
         return self.value(*self.unpack(self.partial()))
+
+
+MB_CHOICE_DT = np.dtype([("link", np.uint32), ("u", np.uint32), ("n", np.uint32), ("n_candidates", np.uint32)])
 
 
 class DeviceMiniBatchSampler:
@@ -514,6 +524,49 @@ class DeviceMiniBatchSampler:
                 return (1, u, n, 0)
             return (0, u, 0, self._candidates_for(self.excluded[u]))
 
+    def choose_many(self, strategy, n):
+        """n consecutive choices as a structured array (link, u, n, n_candidates) -- the same host stream and the same
+        results as n calls of choose(), drawn a block at a time and assembled with numpy (the graph loop hands
+        hundreds of choices to the library per call; a Python loop per choice would be most of its host time)."""
+        out = np.zeros(n, dtype=MB_CHOICE_DT)
+        link_mode = {"Node": None, "NodeLink": True, "NodeNonLink": False}.get(strategy, "bad")
+        if link_mode == "bad":
+            raise AmmsbError("device sampling implements Node / NodeLink / NodeNonLink only")
+        done = 0
+        while done < n:
+            if not self.queue:
+                self._refill()
+            take = min(len(self.queue), n - done)
+            blk = np.array(self.queue[len(self.queue) - take:][::-1], dtype=np.int64)   # pop order
+            coins, us = blk[:, 0], blk[:, 1]
+            is_link = coins.astype(bool) if link_mode is None else np.full(take, link_mode)
+            bad = is_link & (self.degree[us] == 0)
+            if bad.any():   # a link choice on a vertex without edges consumes further queue entries: scalar path
+                first = int(np.flatnonzero(bad)[0])
+                take = first
+            if take:
+                del self.queue[len(self.queue) - take:]
+                seg = out[done:done + take]
+                lk = is_link[:take]
+                seg["link"] = lk
+                seg["u"] = us[:take]
+                seg["n"] = np.where(lk, self.degree[us[:take]], 0)
+                seg["n_candidates"] = np.where(lk, 0, self._cand_table()[(self.excluded[us[:take]] + 31) // 32])
+                done += take
+            if bad.any() and done < n:
+                out[done] = self.choose(strategy)
+                done += 1
+        return out
+
+    def _cand_table(self):
+        """n_candidates by excluded-count bucket (32 per bucket), for choose_many."""
+        t = getattr(self, "_cand_tab", None)
+        if t is None:
+            top = (int(self.excluded.max()) + 31) // 32
+            t = self._cand_tab = np.array([self._candidates_for(32 * b) if b else self._candidates_for(1)
+                                           for b in range(top + 1)], dtype=np.int64)
+        return t
+
     def sizes(self, choice):
         """(n_edges, n_nodes, weight) of a choice."""
         link, u, n, _ = choice
@@ -599,13 +652,15 @@ class GraphLoop:
         ctx.check(ctx.lib.ammsb_loop_create(ctx.handle, C.byref(cfg), C.byref(self._h)))
 
     def run(self, pending, nxt, first_step, parity):
-        n = len(nxt)
-        arr = (_capi.MbChoice * max(n, 1))()
-        for i, ch in enumerate(nxt):
-            arr[i].link, arr[i].u, arr[i].n, arr[i].n_candidates = ch
-        pend = _capi.MbChoice(*pending)
-        self.ctx.check(self.ctx.lib.ammsb_loop_run(self._h, C.byref(pend), arr, n, int(first_step), int(parity),
-                                                   _stream()))
+        """nxt: structured array of MB_CHOICE_DT (DeviceMiniBatchSampler.choose_many) or a list of 4-tuples."""
+        if not isinstance(nxt, np.ndarray):
+            nxt = np.array([tuple(int(x) for x in ch) for ch in nxt], dtype=MB_CHOICE_DT)
+        nxt = np.ascontiguousarray(nxt)
+        n = int(nxt.shape[0])
+        pend = _capi.MbChoice(*[int(x) for x in pending])
+        self.ctx.check(self.ctx.lib.ammsb_loop_run(self._h, C.byref(pend),
+                                                   C.cast(nxt.ctypes.data, C.POINTER(_capi.MbChoice)), n,
+                                                   int(first_step), int(parity), _stream()))
 
     def timestamps(self, first_step, n):
         """(begin_ns, end_ns) arrays of update_phi for steps first_step .. first_step + n - 1.  Synchronises."""

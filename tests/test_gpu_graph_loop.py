@@ -182,3 +182,39 @@ def test_short_minibatch_is_reported(env, small_ds):
     with pytest.raises(ops.AmmsbError):
         smp.check()
     ctx.close()
+
+
+def test_device_sampler_statistics(env, small_ds):
+    """The device sampler is distribution-equivalent to sample.cc:249-303, not stream-equivalent: check the
+    distribution.  Non-link partners uniform over the valid vertices (256-bucket chi-square and a KS distance on the
+    ids), the Node strategy's coin fair, link vertices uniform over the vertices that have an edge."""
+    ops, hostlib, learner, torch = env
+    ds, m = small_ds, 2048
+    ctx, smp, e, v = _sampler(env, ds, m)
+    N = ds.N
+    ids = []
+    for _ in range(24):
+        smp.enqueue(smp.choose("NodeNonLink"), e, v)
+        torch.cuda.synchronize()
+        ids.append(v[1:m + 1].cpu().numpy().view(np.uint32).astype(np.int64))
+    smp.check()
+    ids = np.concatenate(ids)                                   # 49 152 partner ids
+    hist = np.bincount(ids * 256 // N, minlength=256).astype(np.float64)
+    exp = ids.size / 256.0
+    chi2 = ((hist - exp) ** 2 / exp).sum()
+    assert chi2 < 255 + 5 * np.sqrt(2 * 255), chi2              # chi-square(255): mean 255, sd 22.6
+    srt = np.sort(ids) / float(N)
+    ks = np.abs(srt - (np.arange(ids.size) + 0.5) / ids.size).max()
+    assert ks < 1.95 / np.sqrt(ids.size), ks                    # KS critical value at alpha ~ 0.001
+    # the coin and the vertex of 4000 Node-strategy choices
+    picks = [smp.choose("Node") for _ in range(4000)]
+    links = np.array([p[0] for p in picks])
+    assert abs(links.mean() - 0.5) < 4.5 * 0.5 / np.sqrt(links.size)
+    us = np.array([p[1] for p in picks if p[0] == 0])
+    hu = np.bincount(us * 16 // N, minlength=16).astype(np.float64)
+    assert ((hu - us.size / 16.0) ** 2 / (us.size / 16.0)).sum() < 15 + 5 * np.sqrt(30)
+    deg = smp.degree
+    assert all(deg[p[1]] > 0 and p[2] == deg[p[1]] for p in picks if p[0] == 1)   # sampleNodeLink's retry rule
+    # non-link choices carry the candidate count of their vertex
+    assert all(p[3] == smp._candidates_for(smp.excluded[p[1]]) for p in picks if p[0] == 0)
+    ctx.close()

@@ -536,3 +536,41 @@ def test_register_kernels_behind_the_lds_forms():
                           "update_phi or beta_pipeline or perplexity"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+@pytest.mark.parametrize("n_edges,L", [(700, 64), (5000, 64), (3000, 128)])
+def test_beta_gradient_association_order_is_fixed(orc, hip, n_edges, L):
+    """the summation order of the gradient is part of what makes theta / beta reproducible, so it is
+    pinned here: P = min(n_edges, 2048 * 64 / max(wg, 64)) partial rows (a function of the edge count and the
+    work-group size only, never of the CU count), slot s adds edges s, s + P, ... in order, and the rows are added as
+    sum_partials8 does (row-lane r takes rows r, r + 128, ... ascending, then the halving tree).  Emulated in numpy from
+    the oracle's per-edge terms, the result must equal the HIP gradient bit for bit."""
+    N, K = 4096, 64 if L == 64 else 256
+    pr = Problem(orc, hip, N, K, 8, 16)
+    rng = pr.rng
+    non = orc.make_edge(rng.integers(0, N, n_edges), rng.integers(0, N, n_edges))
+    mbe = np.concatenate([pr.edges[: n_edges // 4], non[: n_edges - n_edges // 4]]).astype(np.uint64)
+    rng.shuffle(mbe)
+    upd = hip.BetaUpdater(pr.ctx, pr.theta, pr.beta, pr.pi, pr.dset, (44, 45), L)
+    got = upd.calculate_grads(pr.ctx.from_numpy(mbe), mbe.size).cpu().numpy()
+    # per-edge terms: the oracle's gradient of a one-edge mini-batch is that edge's term exactly (0 + x == x)
+    terms = np.stack([orc.beta_grads(pr.p_orc, pr.theta_h, pr.beta_h, pr.pi_h.reshape(-1), pr.oset, mbe[i:i + 1], L, 1, order=0)
+                      for i in range(mbe.size)])
+    P = min(mbe.size, 2048 * 64 // max(L, 64))
+    rows = np.zeros((P, 2 * K), dtype=np.float32)
+    for s in range(P):
+        acc = np.zeros(2 * K, dtype=np.float32)
+        for e in range(s, mbe.size, P):
+            acc = acc + terms[e]
+        rows[s] = acc
+    lanes = np.zeros((128, 2 * K), dtype=np.float32)
+    for r in range(128):
+        acc = np.zeros(2 * K, dtype=np.float32)
+        for p in range(r, P, 128):
+            acc = acc + rows[p]
+        lanes[r] = acc
+    half = 64
+    while half > 0:
+        lanes[:half] = lanes[:half] + lanes[half:2 * half]
+        half //= 2
+    assert np.array_equal(got.view(np.uint32), lanes[0].view(np.uint32))
