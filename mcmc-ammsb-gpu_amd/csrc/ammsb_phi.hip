@@ -508,6 +508,235 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 4
   if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Short rows (K = 256 / 512: KPT = 4 / 8, one wave per node): TWO neighbour rows per loop iteration.
+//
+// (U rows per iteration, U = 2 or 4; the text below says two.)
+// With 1 KiB rows the single-row loop above is latency-bound, not bandwidth-bound: an iteration is a dependent
+// chain LDS read -> probs -> wave tree sum -> divisions -> LDS, about a microsecond, whatever the ring depth, and
+// there are not enough nodes in a mini-batch (8193 at C2) to hide it with more waves.  Here the chains of rows q and
+// q + 1 are issued together as one straight-line block (no branch between them: the link / non-link sign is a
+// multiplication by +-1, which is exact, instead of two code copies), so the scheduler interleaves two independent
+// chains per wave.  Every value is computed by the same operations in the same order as in the single-row kernel:
+// results are bit-identical (same tests).  Needs an even n; odd n takes the single-row kernel.
+template <int KPT, int D, int U>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void update_phi_lds2_kernel(const PhiArgs a) {
+  constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
+  static_assert(D > U && (D & (D - 1)) == 0 && (U == 2 || U == 4) && (D - U) * PIECES <= 63, "ring depth / rows per step");
+  extern __shared__ __align__(16) char smem[];  // [D][KW] ring, [KW] normals, [n] u32 (id | link bit)
+  __shared__ ZigTables zig;
+  const int tid = threadIdx.x, ln = tid;
+  float* ring = reinterpret_cast<float*>(smem);
+  float* s_noise = ring + D * KW;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + (D + 1) * KW * sizeof(float));
+
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, 0);
+  const uint32_t g = a.group_begin + blockIdx.x;
+  if (g >= st.group_end) return;  // block-uniform
+  const uint32_t n = a.n;
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  f32x2 bf[HP];
+  bool beta_safe = true;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    const float b0 = a.beta[2 * (tid + 2 * L * p) + 1];
+    const float b1 = a.beta[2 * (tid + 2 * L * p + L) + 1];
+    bf[p] = f32x2{b0 - EPS, b1 - EPS};
+    beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
+  }
+  ammsb_seed rs = {0, 0};
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * L + tid];
+
+  auto request = [&](uint32_t q, uint32_t slot) {
+    const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
+    const float* src = rpm_row(a.pi, nbr) + 4 * tid;
+    char* dst = smem + slot * (KW * sizeof(float));
+#pragma unroll
+    for (int t = 0; t < PIECES; ++t)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+  };
+
+  for (uint64_t i = g; i < st.n_nodes; i += st.G) {
+    const uint32_t node = a.nodes[i];
+    __syncthreads();  // orders the LDS traffic of consecutive nodes
+    for (uint32_t q = tid; q < n; q += L) {
+      const uint32_t nb = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nb));
+      s_nb[q] = nb | (y ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+
+    const float phi_sum = a.phi_sum[node];
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = rpm_row(a.pi, node);
+    f32x2 pi_a[HP], grads[HP], rden[HP];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+    for (int p = 0; p < HP; ++p)
+      pi_a[p] = f32x2{__builtin_nontemporal_load(row_a + tid + 2 * L * p), __builtin_nontemporal_load(row_a + tid + 2 * L * p + L)};
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)(D - U); ++r)
+      if (r < n) request(r, r);  // rows 0 .. D-U-1 fly during the per-node set-up
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      grads[p] = f32x2{0.0f, 0.0f};
+      const f32x2 den = pi_a[p] * phi_sum;
+      rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
+      node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
+      const f32x2 ep = den * st.eps_t;
+      s_noise[ln + 128 * p] = sqrtf(ep.x);
+      s_noise[ln + 128 * p + 64] = sqrtf(ep.y);
+    }
+
+    for (uint32_t q = 0; q < n; q += U) {  // n is a multiple of U (dispatch)
+      float* row[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) row[r] = ring + ((q + r) & (D - 1)) * KW;
+      // every LDS read of rows q-U .. q-1 has been consumed; their slots take rows q+D-U .. q+D-1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (q + (D - U) < n) {  // n a multiple of U: all U rows exist
+#pragma unroll
+        for (int r = 0; r < U; ++r) request(q + (D - U) + r, (q + (D - U) + r) & (D - 1));
+      }
+      // U of the lane's KPT normals per iteration, drawn while the rows are on their way (ascending column order)
+      if (a.noise_on) {
+#pragma unroll
+        for (int r = 0; r < U; ++r)
+          if (q + r < (uint32_t)KPT) s_noise[ln + 64 * (q + r)] = s_noise[ln + 64 * (q + r)] * rng_normal(rs, &zig);
+      }
+      {  // rows q .. q+U-1 landed; rows q+U .. min(q+D-1, n-1) may still be in flight (a multiple of U of them)
+        const uint32_t rem = n - U - q < (uint32_t)(D - U) ? n - U - q : (uint32_t)(D - U);
+        if (rem >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PIECES) : "memory");
+        else if (rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PIECES) : "memory");
+        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      float ee[U], sg[U], part[U], lo[U], psum[U];
+      bool fast[U], all_fast = true;
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        const bool y = (__builtin_amdgcn_readfirstlane(s_nb[q + r]) >> 31) != 0;
+        ee[r] = y ? EPS : 1.0f - EPS;
+        // pin * (EPS - beta) + e == e - pin * (beta - EPS) == e + (-(pin * (beta - EPS))): the negation is exact, so
+        // multiplying by -1 for a non-link and adding gives the single-row kernel's value bit for bit
+        sg[r] = y ? 1.0f : -1.0f;
+        part[r] = 0.0f;
+        lo[r] = 1.0f;
+      }
+      // pass 1 of all U rows (phi.cc:241-253): probs[] in place of the row, lane partials in ascending column order
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const f32x2 pin = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
+          const f32x2 tt = (pin * bf[p]) * sg[r] + ee[r];
+          const f32x2 pr = pi_a[p] * tt;
+          row[r][ln + 128 * p] = pr.x;
+          row[r][ln + 128 * p + 64] = pr.y;
+          part[r] += pr.x;
+          part[r] += pr.y;
+          lo[r] = fminf(fminf(lo[r], fabsf(pr.x)), fabsf(pr.y));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        psum[r] = Group<64>::wave_tree64(part[r]);  // phi.cc:254-257
+        fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
+        all_fast = all_fast && fast[r];
+      }
+      // pass 2 (phi.cc:259-263): grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum, rows in order
+      if (all_fast) {
+        float ps = phi_sum;
+        asm volatile("" : "+v"(ps));  // keeps pi_a * phi_sum from being hoisted into KPT more registers
+        f32x2 s2[U], r2[U];
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const float rc = exact_rcp(psum[r]);
+          s2[r] = f32x2{psum[r], psum[r]};
+          r2[r] = f32x2{rc, rc};
+        }
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 den = pi_a[p] * ps;
+          f32x2 v[U];
+#pragma unroll
+          for (int r = 0; r < U; ++r) {
+            const f32x2 pr = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
+            v[r] = div_exact3(div_exact3(pr, s2[r], r2[r]), den, rden[p]);
+          }
+#pragma unroll
+          for (int r = 0; r < U; ++r) grads[p] += v[r] - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const float probs_sum = psum[r];
+          if (fast[r]) {
+            const float rps = exact_rcp(probs_sum);
+            float ps = phi_sum;
+            asm volatile("" : "+v"(ps));
+            const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+              const f32x2 pr = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
+              f32x2 qv = div_exact3(pr, psum2, rps2);
+              qv = div_exact3(qv, pi_a[p] * ps, rden[p]);
+              grads[p] += qv - inv_phi_sum;
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+              const f32x2 den = pi_a[p] * phi_sum;
+              float v0 = row[r][ln + 128 * p] / probs_sum;
+              float v1 = row[r][ln + 128 * p + 64] / probs_sum;
+              v0 = v0 / den.x;
+              v1 = v1 / den.y;
+              grads[p] += f32x2{v0 - inv_phi_sum, v1 - inv_phi_sum};
+            }
+          }
+        }
+      }
+    }
+
+    // normals the loop did not get to (n < KPT): one rolled loop, a single copy of the ziggurat code
+    if (a.noise_on) {
+#pragma unroll 1
+      for (uint32_t j = n; j < (uint32_t)KPT; ++j) s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // SGLD step, phi.cc:265-274
+    float* out = a.phi_vec + i * K;
+    const float half = st.eps_t / 2;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      const f32x2 bb = f32x2{s_noise[ln + 128 * p], s_noise[ln + 128 * p + 64]};
+      const f32x2 phi_k = pi_a[p] * phi_sum;
+      const f32x2 ng = grads[p] * a.Nn;
+      f32x2 in = a.alpha - phi_k;
+      in = in + ng;
+      const f32x2 drift = in * half;
+      const f32x2 aa = phi_k + drift;
+      const f32x2 s2 = aa + bb;
+      const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
+      __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + tid + 2 * L * p);
+      __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
+    }
+  }
+  if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
+}
+
+template <int KPT, int D, int U>
+int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = (size_t)(D + 1) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  update_phi_lds2_kernel<KPT, D, U><<<n_groups, 64, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 template <int KPT, int W, int D = 2>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t lds = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
@@ -673,10 +902,13 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
         case 4:
           if (ring == 2) return launch_phi_lds<4, 1, 2>(ctx, a, n_groups, s);
           if (ring == 4) return launch_phi_lds<4, 1, 4>(ctx, a, n_groups, s);
-          return launch_phi_lds<4, 1, 8>(ctx, a, n_groups, s);
+          if (ring == 8 || (a.n & 1)) return launch_phi_lds<4, 1, 8>(ctx, a, n_groups, s);
+          if (ring == 22 || (a.n & 3)) return launch_phi_lds2<4, 8, 2>(ctx, a, n_groups, s);  // two rows per iteration
+          return launch_phi_lds2<4, 8, 4>(ctx, a, n_groups, s);                               // four (n % 4 == 0)
         case 8:
           if (ring == 2) return launch_phi_lds<8, 1, 2>(ctx, a, n_groups, s);
-          return launch_phi_lds<8, 1, 4>(ctx, a, n_groups, s);
+          if (ring == 4 || (a.n & 1)) return launch_phi_lds<8, 1, 4>(ctx, a, n_groups, s);
+          return launch_phi_lds2<8, 4, 2>(ctx, a, n_groups, s);
         case 16: return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
         case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);
       }

@@ -269,7 +269,11 @@ PHI_CASES = [
     (2048, 64, 8, 300, 64),
     (2048, 64, 8, 300, 32),
     (2048, 32, 8, 300, 64),     # K < L: half the lanes idle
-    (2048, 256, 32, 200, 64),
+    (2048, 256, 32, 200, 64),   # short rows: two neighbour rows per iteration (update_phi_lds2_kernel<4, 8>)
+    (2048, 512, 32, 100, 64),   # update_phi_lds2_kernel<8, 4>
+    (2048, 256, 5, 100, 64),    # odd n: the single-row kernel with the deep ring
+    (2048, 256, 2, 100, 64),    # fewer neighbours than ring slots
+    (2048, 512, 6, 100, 64),
     (2048, 256, 32, 200, 128),
     (2048, 256, 32, 200, 256),
     (1024, 1000, 5, 64, 64),    # K not a multiple of L, odd n
