@@ -214,9 +214,11 @@ int ammsb_minibatch_nonlink(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_candid
 
 /* ---- whole iterations as captured hipGraphs (new; replaces the launch-then-Finish discipline of
  *      learner.cc:237-242, phi.cc:755-761, beta.cc:339-383 where the iteration is launch-latency-bound) ----
- * One ammsb_loop owns eight small graphs: [update_phi, update_pi, beta gradient, theta/beta step] of THIS step
- * (main stream) and [mini-batch + neighbour sampling of the NEXT step] (sampler stream), each specialised by
- * (link batch?, buffer parity); a learner iteration with device-side mini-batch sampling is one launch of each.  The per-step scalars (sizes, eps_t, weight, u) are read by the kernels from device-resident
+ * One ammsb_loop owns 24 small graphs: [update_phi, update_pi, beta gradient, theta/beta step] of step i (main
+ * stream) and [mini-batch + neighbour sampling of the mini-batch of step i + 2] (sampler stream), each specialised by
+ * (link batch?, buffer set, parity); a learner iteration with device-side mini-batch sampling is one launch of each.
+ * Sampling runs two steps ahead through three buffer sets (the caller's two and one the loop allocates); a run starts
+ * from the caller's one pending mini-batch and leaves exactly one pending mini-batch in the caller's buffers.  The per-step scalars (sizes, eps_t, weight, u) are read by the kernels from device-resident
  * descriptors the loop uploads a chunk at a time, so a step costs the host two hipGraphLaunch calls and two events.
  * Same kernels, same arguments, same per-stream order as the eager entry points above: the trajectory is
  * bit-identical to calling them one by one.  The caller keeps choosing (link?, u) per mini-batch, as with the
@@ -224,7 +226,6 @@ int ammsb_minibatch_nonlink(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t n_candid
 typedef struct ammsb_loop ammsb_loop;
 
 #define AMMSB_LOOP_TIMESTAMPS 1u /* update_phi / update_pi note the device time at which their first block starts */
-#define AMMSB_LOOP_SERIAL 2u     /* one graph per step on one stream (sampling chain in line) instead of two streams */
 
 typedef struct {
   /* model state (learner.cc:80-91) */
@@ -259,6 +260,8 @@ typedef struct {
   uint32_t* mb_count;
   uint32_t mini_batch;  /* m */
   uint32_t max_fan_out; /* largest training degree: link batches are launched for this size */
+  uint32_t max_nodes;   /* capacity of nodes[] (rows of neighbors[] / nbr_table[]): max(2m, 1 + max_fan_out), phi.cc:620-622 */
+  uint32_t max_edges;   /* capacity of edges[]: max(m, max_fan_out), sample.cc:129 */
   uint32_t flags;       /* AMMSB_LOOP_* */
 } ammsb_loop_config;
 

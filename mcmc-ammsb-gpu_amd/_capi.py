@@ -53,7 +53,7 @@ class LoopConfig(C.Structure):  # ammsb_loop_config
                 ("nbr_seeds", _vp * 2), ("nbr_wg", _u32),
                 ("csr_offsets", _vp), ("csr_targets", _vp), ("mb_seeds", _vp), ("mb_candidates", _u32),
                 ("mb_workspace", _vp), ("mb_count", _vp), ("mini_batch", _u32), ("max_fan_out", _u32),
-                ("flags", _u32)]
+                ("max_nodes", _u32), ("max_edges", _u32), ("flags", _u32)]
 
 
 class MbChoice(C.Structure):  # ammsb_mb_choice

@@ -411,6 +411,82 @@ __global__ __launch_bounds__(64) void sample_neighbors_lds_kernel(ammsb_seed* se
   if (owner) seeds[gid] = seed;
 }
 
+// n = 32 (capacity 2n = 64 = one wave): ONE WAVE PER STREAM.  The per-thread kernels above run the reference's
+// algorithm as written -- one lane per node, a dependent chain of n draws, each a 64-bit modulo, a hash and a table
+// probe -- and take ~1.2 us per draw whatever the node count (latency-bound: 33 nodes 32 us, 8193 nodes 42 us), which
+// made the sampler chain the longest thing in a small iteration.  Here the same sequence is produced with the work
+// split by what is actually sequential:
+//   1. the xorshift128+ stream: all lanes step it together (wave-uniform arithmetic), lane j keeps output j and the
+//      state after it -- B raw draws per batch;
+//   2. every lane reduces ITS draw modulo N and hashes it (the expensive part: once, in parallel, not per draw);
+//   3. the open-addressing table IS the wave: slot s lives in lane s.  Draws are consumed in stream order; "is it
+//      there already" is one ballot, "first free slot at or after h" a rotate + find-first-set on the occupancy mask.
+// The table image, the packed result (table entries in slot order, sample.cc:64-76) and the stream state after the
+// last consumed draw are those of the per-thread kernel bit for bit (same tests).
+__global__ __launch_bounds__(256) void sample_neighbors_wave_kernel(ammsb_seed* seeds, const uint32_t* nodes,
+                                                                     uint32_t n_nodes, uint32_t N, uint32_t gsize,
+                                                                     uint32_t* table, uint32_t* packed,
+                                                                     const ammsb_step_desc* desc, uint32_t wg) {
+  constexpr uint32_t CAP = 64, NN = 32, B = 40;  // capacity, neighbours per node, raw draws per batch
+  if (desc) {
+    n_nodes = desc->n_nodes;
+    gsize = ns_global_size(n_nodes, wg);
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t gid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // stream = wave
+  if (gid >= gsize || gid >= n_nodes) return;  // wave-uniform
+  ammsb_seed st = seeds[gid];
+  const FastMod mod_n = fast_mod_init((uint64_t)N);
+  for (uint32_t i = gid; i < n_nodes; i += gsize) {
+    const uint32_t node = nodes[i];
+    uint32_t slot = N;  // lane s = table slot s; N marks an empty slot (sample.cc:57)
+    uint32_t count = 0;
+    while (count < NN) {
+      // 1. B raw draws from the stream; lane j keeps draw j and the state after it
+      ammsb_seed run = st, mine = st;
+      uint64_t raw = 0;
+#pragma unroll 8
+      for (uint32_t j = 0; j < B; ++j) {
+        const uint64_t x = rng_next(run);
+        if (lane == j) {
+          raw = x;
+          mine = run;
+        }
+      }
+      // 2. randint(seed, 0, N - 1) and the slot hash of this lane's draw
+      const uint32_t r = (uint32_t)fast_mod(raw, mod_n);
+      const uint32_t h = (r ^ 553105253u) & (CAP - 1);  // (r ^ c) % capacity; the probe step 1 + 2 capacity is 1
+      // 3. consume the draws in stream order
+      uint32_t used = 0;
+      for (uint32_t j = 0; j < B && count < NN; ++j) {
+        used = j + 1;
+        const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)j);
+        if (rj == node) continue;                                  // do { r = randint } while (r == node)
+        if (__ballot(slot == rj) != 0ull) continue;                // already in the table: draw again
+        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)j);
+        const unsigned long long freeb = ~__ballot(slot != N);     // never zero: at most 32 of 64 slots are taken
+        const unsigned long long rot = hj ? ((freeb >> hj) | (freeb << (64 - hj))) : freeb;
+        const uint32_t pos = (hj + (uint32_t)__builtin_ctzll(rot)) & (CAP - 1);
+        if (lane == pos) slot = rj;
+        ++count;
+      }
+      // the stream stands after the last draw consumed
+      auto lane64 = [&](uint64_t v) -> uint64_t {  // (readlane returns int: cast before widening)
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(used - 1));
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(used - 1));
+        return ((uint64_t)hi << 32) | lo;
+      };
+      st.x = lane64(mine.x);
+      st.y = lane64(mine.y);
+    }
+    // table image (GetHash()) and the packed result: occupied slots in slot order
+    table[(uint64_t)i * CAP + lane] = slot;
+    const unsigned long long occ = __ballot(slot != N);
+    if (slot != N) packed[(uint64_t)i * NN + __popcll(occ & ((1ull << lane) - 1ull))] = slot;
+  }
+  if (lane == 0) seeds[gid] = st;
+}
+
 static int sample_neighbors_common(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes,
                                    uint32_t wg, uint32_t* table, uint32_t* packed, const ammsb_step_desc* desc,
                                    void* stream) {
@@ -421,7 +497,17 @@ static int sample_neighbors_common(ammsb_ctx* ctx, ammsb_seed* seeds, const uint
   AMMSB_CHECK_ARG(ctx, ctx->params.N > (uint64_t)n + 1, "N must exceed num_node_sample + 1");
   const uint32_t gsize = ns_global_size(n_nodes, wg);  // sample.cc:116-119
   const size_t lds_bytes = (size_t)2 * n * 65 * sizeof(uint32_t);
-  if (lds_bytes <= 64 * 1024)
+  static const bool per_thread = [] {  // AMMSB_NBR_FORM=t: the per-thread kernels where the wave form would be picked
+    const char* f = getenv("AMMSB_NBR_FORM");
+    return f && f[0] == 't';
+  }();
+  // one wave per stream pays while there are few streams (33 nodes: 8 vs 32 us, 8193: 23 vs 42 us); with 65537 of
+  // them the chip is full either way and 64 nodes per wave use it better (72 vs 132 us)
+  if (n == 32 && !per_thread && n_nodes <= 20000) {
+    const uint32_t waves = gsize < n_nodes ? gsize : n_nodes;
+    sample_neighbors_wave_kernel<<<div_up(waves, 4), 256, 0, as_stream(stream)>>>(
+        seeds, nodes, n_nodes, (uint32_t)ctx->params.N, gsize, table, packed, desc, wg);
+  } else if (lds_bytes <= 64 * 1024)
     sample_neighbors_lds_kernel<<<div_up(gsize, 64), 64, lds_bytes, as_stream(stream)>>>(
         seeds, nodes, n_nodes, (uint32_t)ctx->params.N, n, gsize, table, packed, desc, wg);
   else

@@ -3,19 +3,23 @@
 // The reference's loop (mcmc/learner.cc:222-247) launches one kernel at a time and waits for each
 // (queue.Finish() in phi.cc:755-761, beta.cc:339-383): seven launch + wait pairs per iteration, which is what
 // an iteration costs at the small configurations (N = 10k..100k: a few tens of microseconds of device work).
-// Here one iteration is two hipGraphLaunch calls on two streams: the sampling chain of the NEXT mini-batch
-// (sampler stream) runs beside update_phi, update_pi, the beta gradient, its partial-row sum and the theta/beta
-// step of THIS mini-batch (main stream); two events per step order the double buffer.  (A fork/join inside one
-// graph costs ~40 us per replay on this runtime and a single in-line chain exposes the sampler's latency; both
-// were measured, tools/gpu_exp.sh.  AMMSB_LOOP_SERIAL keeps the single-stream form: one launch per step.)
+// Here one iteration is two hipGraphLaunch calls on two streams: the MAIN chain of step i (update_phi, update_pi,
+// the beta partial rows, one kernel for their sum and the theta/beta step) and the SAMPLER chain that produces the
+// mini-batch of step i + 2 (mini-batch kernels + neighbour sampler).  Sampling runs TWO steps ahead through three
+// buffer sets (the caller's two Sample buffers and one of the loop's own), so a short step -- a link batch is a few
+// dozen edges -- does not wait for the ~60 us sampling chain of a 65536-edge batch; events order the ring
+// (sampler(i) waits for main(i-1), main(i) for sampler(i-2)).  A run starts with the caller's one pending
+// mini-batch and ends with exactly one pending mini-batch in the caller's buffer, as the eager loop does, so the
+// two forms can alternate and a checkpoint needs nothing new.  (A fork/join inside ONE graph costs ~40 us per
+// replay on this runtime, an in-line chain exposes the sampler's latency, one step of look-ahead leaves every
+// link step waiting for the next non-link batch's sampling: all three were measured)
 //
 // What changes from step to step (mini-batch sizes, eps_t, the sampler's vertex u) cannot be a kernel
 // parameter of a captured graph.  It lives in device memory instead (ammsb_step_desc, ammsb_step.h): the host
-// uploads the descriptors of the next <= CHUNK steps in one copy, and the last kernel of every step
-// (update_theta) hands the following two descriptors to the graph that runs next.  Graphs are specialised by
-// (link batch?, buffer parity) -- four main-chain and four sampler graphs, captured once.  A link
-// batch has deg(u) edges, so its kernels are launched for the largest degree and read the real size from the
-// descriptor; surplus blocks leave at once.
+// uploads the descriptors of the next <= CHUNK steps in one copy, and the last kernel of every step hands the
+// following descriptors to the graphs that run next.  Graphs are specialised by (link batch?, physical buffer,
+// parity): 24 small linear graphs, captured once.  A link batch has deg(u) edges, so its kernels are launched for
+// the largest degree and read the real size from the descriptor; surplus blocks leave at once.
 //
 // Every kernel is the one the eager C ABI launches, with the same arguments in the same per-stream order, so
 // the trajectory is bit-identical to the eager loop's (tests/test_gpu_graph_loop.py).
@@ -28,20 +32,28 @@
 
 namespace {
 
-constexpr uint32_t CHUNK = 1024;      // steps per descriptor upload
+constexpr uint32_t CHUNK = 1024;                 // steps per descriptor upload
 constexpr uint32_t STAMP_CAP = AMMSB_STAMP_CAP;  // steps whose update_phi timestamps are kept
+constexpr int NBUF = 3;                          // sample buffer sets: the caller's two + one of the loop's own
 
 __global__ void loop_prime_kernel(const ammsb_step_desc* ring, uint32_t* cursor, ammsb_step_desc* cur,
                                   ammsb_step_desc* nxt) {
-  *cur = ring[0];
-  *nxt = ring[1];
+  *cur = ring[0];  // the step that runs next
+  *nxt = ring[2];  // the mini-batch its sampler chain produces (two steps ahead)
   *cursor = 0;
 }
 
 struct Stage {
-  ammsb_step_desc* ring;  // pinned host staging, [CHUNK + 2]
+  ammsb_step_desc* ring;  // pinned host staging, [CHUNK + 4]
   hipEvent_t done;        // the upload that read it has executed
   bool used;
+};
+
+struct SampleBuf {  // one mini-batch: edges, nodes, the neighbour sampler's packed result and table image
+  uint64_t* edges;
+  uint32_t* nodes;
+  uint32_t* neighbors;
+  uint32_t* nbr_table;
 };
 
 }  // namespace
@@ -53,20 +65,21 @@ struct ammsb_loop {
   ammsb_set training, heldout;
   bool has_heldout;
   hipStream_t main, side;
-  hipEvent_t ev_in, ev_out, ev_prime;
-  hipEvent_t ev_main[2], ev_samp[2];  // step i's main chain / sampler chain finished (alternating)
-  ammsb_step_desc* d_ring;  // [CHUNK + 2]
+  hipEvent_t ev_in, ev_out, ev_prime, ev_first;
+  hipEvent_t ev_main[NBUF], ev_samp[NBUF];  // step i's main chain / sampler chain finished (i % 3)
+  SampleBuf buf[NBUF];                      // [0], [1]: the caller's Sample buffers; [2]: owned
+  void* own_mem;                            // the allocation behind buf[2]
+  ammsb_step_desc* d_ring;                  // [CHUNK + 4]
   uint32_t* d_cursor;
-  ammsb_step_desc* d_cur[2];
-  ammsb_step_desc* d_nxt[2];
+  ammsb_step_desc* d_cur[2];     // descriptor of the step that runs next, by step parity
+  ammsb_step_desc* d_nxt[NBUF];  // descriptor of the mini-batch being sampled into buffer set b (a sampler chain may
+                                 // still be reading it two main chains later: one per buffer set, not per parity)
   unsigned long long* d_stamps;  // [STAMP_CAP][2] or null
   Stage stage[2];
   int next_stage;
-  hipGraphExec_t exec[2][2][2];  // serial form: [this step link][next step link][parity]
-  hipGraphExec_t exec_main[2][2];  // [this step link][parity]
-  hipGraphExec_t exec_samp[2][2];  // [next step link][parity of THIS step]
-  bool serial;
-  uint32_t link_nodes_cap, link_edges_cap;
+  hipGraphExec_t exec_main[2][NBUF][2];  // [this step link][physical buffer read][descriptor parity]
+  hipGraphExec_t exec_samp[2][NBUF][2];  // [sampled batch link][physical buffer written][descriptor parity]
+  uint32_t link_nodes_cap, link_edges_cap, n_nbr;
   float w_link, w_nonlink;
   int wall_khz;
   uint64_t graphs_launched;
@@ -89,50 +102,51 @@ namespace {
     if (rc_ != AMMSB_OK) return rc_; \
   } while (0)
 
-// the sampling chain of the NEXT mini-batch into the other buffer pair (sample.cc:249-303 + learner.cc:162-194)
-int record_sampler(ammsb_loop* lp, int nl, int p, hipStream_t st) {
+// the sampling chain of one mini-batch (sample.cc:249-303 + learner.cc:162-194) into buffer set `b`, with the
+// neighbour-sampler streams of Sample[sp]; the sizes / vertex come from `desc`
+int record_sampler(ammsb_loop* lp, int nl, int b, int sp, const ammsb_step_desc* desc, hipStream_t st) {
   const ammsb_loop_config& c = lp->c;
   ammsb_ctx* ctx = lp->ctx;
-  const int q = 1 - p;
-  const ammsb_step_desc* nxt = lp->d_nxt[p];
+  const SampleBuf& o = lp->buf[b];
   const uint32_t m = c.mini_batch;
   if (nl)
-    LOOP_RC(ammsb_minibatch_link_d(ctx, c.csr_offsets, c.csr_targets, lp->link_edges_cap, c.edges[q], c.nodes[q], nxt, st));
+    LOOP_RC(ammsb_minibatch_link_d(ctx, c.csr_offsets, c.csr_targets, lp->link_edges_cap, o.edges, o.nodes, desc, st));
   else
     LOOP_RC(ammsb_minibatch_nonlink_d(ctx, c.mb_seeds, c.mb_candidates, m, &lp->training,
-                                      lp->has_heldout ? &lp->heldout : nullptr, c.mb_workspace, c.edges[q], c.nodes[q],
-                                      c.mb_count, nxt, st));
-  LOOP_RC(ammsb_sample_neighbors_d(ctx, c.nbr_seeds[q], c.nodes[q], nl ? lp->link_nodes_cap : m + 1, c.nbr_wg,
-                                   c.nbr_table[q], c.neighbors[q], nxt, st));
+                                      lp->has_heldout ? &lp->heldout : nullptr, c.mb_workspace, o.edges, o.nodes,
+                                      c.mb_count, desc, st));
+  LOOP_RC(ammsb_sample_neighbors_d(ctx, c.nbr_seeds[sp], o.nodes, nl ? lp->link_nodes_cap : m + 1, c.nbr_wg, o.nbr_table,
+                                   o.neighbors, desc, st));
   return AMMSB_OK;
 }
 
-// this step's chain (learner.cc:237-242)
-int record_main(ammsb_loop* lp, int cl, int p, hipStream_t st) {
+// one step's chain (learner.cc:237-242) over buffer set `b`, descriptor parity dp
+int record_main(ammsb_loop* lp, int cl, int b, int dp, hipStream_t st) {
   const ammsb_loop_config& c = lp->c;
   ammsb_ctx* ctx = lp->ctx;
-  const int q = 1 - p;
-  const ammsb_step_desc* cur = lp->d_cur[p];
+  const SampleBuf& in = lp->buf[b];
+  const ammsb_step_desc* cur = lp->d_cur[dp];
   const uint32_t m = c.mini_batch;
   const uint32_t cap_nodes = cl ? lp->link_nodes_cap : m + 1;
   const uint32_t cap_edges = cl ? lp->link_edges_cap : m;
   // (AMMSB_LOOP_TIMESTAMPS) block 0 of update_phi and block 0 of update_pi note the device time they start at
-  LOOP_RC(ammsb_update_phi_d(ctx, c.beta, &lp->pi, c.phi_sum, &lp->training, c.nodes[p], c.neighbors[p], cap_nodes,
+  LOOP_RC(ammsb_update_phi_d(ctx, c.beta, &lp->pi, c.phi_sum, &lp->training, in.nodes, in.neighbors, cap_nodes,
                              c.phi_seeds, c.phi_wg, c.phi_flags, c.phi_vec, cur, lp->d_stamps, st));
-  LOOP_RC(ammsb_update_pi_d(ctx, &lp->pi, c.phi_sum, c.phi_vec, c.nodes[p], cap_nodes, c.phi_wg, cur, lp->d_stamps, st));
-  const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[q], lp->d_nxt[q]};
-  LOOP_RC(ammsb_beta_step_d(ctx, c.theta, c.beta, &lp->pi, &lp->training, c.edges[p], cap_edges, c.beta_wg, c.grads,
+  LOOP_RC(ammsb_update_pi_d(ctx, &lp->pi, c.phi_sum, c.phi_vec, in.nodes, cap_nodes, c.phi_wg, cur, lp->d_stamps, st));
+  // the last kernel hands ring[c + 1] (next step) and ring[c + 3] over: the batch the next step's sampler chain
+  // produces -- into the buffer set this step has just finished reading
+  const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[1 - dp], lp->d_nxt[b], 3u};
+  LOOP_RC(ammsb_beta_step_d(ctx, c.theta, c.beta, &lp->pi, &lp->training, in.edges, cap_edges, c.beta_wg, c.grads,
                             c.beta_seeds, c.beta_flags, cur, &adv, st));
   return AMMSB_OK;
 }
 
-// kind 0: sampler chain + main chain in line (serial form), 1: main chain, 2: sampler chain
-int capture(ammsb_loop* lp, int kind, int cl, int nl, int p, hipGraphExec_t* out) {
+// kind 1: main chain, 2: sampler chain (reading d_nxt[b]; its neighbour-sampler streams are Sample[dp]'s: the batch
+// sampled during step i is consumed by step i + 2, which has the same parity)
+int capture(ammsb_loop* lp, int kind, int link, int b, int dp, hipGraphExec_t* out) {
   hipStream_t st = kind == 2 ? lp->side : lp->main;
   LOOP_HIP(lp, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  int rc = AMMSB_OK;
-  if (kind == 0 || kind == 2) rc = record_sampler(lp, nl, p, st);
-  if (rc == AMMSB_OK && (kind == 0 || kind == 1)) rc = record_main(lp, cl, p, st);
+  const int rc = kind == 2 ? record_sampler(lp, link, b, dp, lp->d_nxt[b], st) : record_main(lp, link, b, dp, st);
   hipGraph_t g = nullptr;
   const hipError_t e = hipStreamEndCapture(st, &g);
   if (rc != AMMSB_OK) {
@@ -157,22 +171,21 @@ void destroy(ammsb_loop* lp) {
   if (lp->main) (void)hipStreamSynchronize(lp->main);
   if (lp->side) (void)hipStreamSynchronize(lp->side);
   for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b)
-      for (int p = 0; p < 2; ++p)
-        if (lp->exec[a][b][p]) (void)hipGraphExecDestroy(lp->exec[a][b][p]);
-  for (int a = 0; a < 2; ++a)
-    for (int p = 0; p < 2; ++p) {
-      if (lp->exec_main[a][p]) (void)hipGraphExecDestroy(lp->exec_main[a][p]);
-      if (lp->exec_samp[a][p]) (void)hipGraphExecDestroy(lp->exec_samp[a][p]);
-    }
+    for (int b = 0; b < NBUF; ++b)
+      for (int p = 0; p < 2; ++p) {
+        if (lp->exec_main[a][b][p]) (void)hipGraphExecDestroy(lp->exec_main[a][b][p]);
+        if (lp->exec_samp[a][b][p]) (void)hipGraphExecDestroy(lp->exec_samp[a][b][p]);
+      }
   for (Stage& st : lp->stage) {
     if (st.ring) (void)hipHostFree(st.ring);
     if (st.done) (void)hipEventDestroy(st.done);
   }
-  for (hipEvent_t ev : {lp->ev_in, lp->ev_out, lp->ev_prime, lp->ev_main[0], lp->ev_main[1], lp->ev_samp[0], lp->ev_samp[1]})
+  for (hipEvent_t ev : {lp->ev_in, lp->ev_out, lp->ev_prime, lp->ev_first, lp->ev_main[0], lp->ev_main[1], lp->ev_main[2],
+                        lp->ev_samp[0], lp->ev_samp[1], lp->ev_samp[2]})
     if (ev) (void)hipEventDestroy(ev);
   if (lp->d_ring) (void)hipFree(lp->d_ring);  // one allocation: ring, cursor, cur/nxt
   if (lp->d_stamps) (void)hipFree(lp->d_stamps);
+  if (lp->own_mem) (void)hipFree(lp->own_mem);
   if (lp->side) (void)hipStreamDestroy(lp->side);
   if (lp->main) (void)hipStreamDestroy(lp->main);
   delete lp;
@@ -212,6 +225,8 @@ int check_choice(ammsb_loop* lp, const ammsb_mb_choice& ch) {
   return AMMSB_OK;
 }
 
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 }  // namespace
 
 extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, ammsb_loop** out) {
@@ -227,6 +242,9 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
                   "null mini-batch sampler buffer");
   AMMSB_CHECK_ARG(ctx, c.mini_batch > 0 && c.max_fan_out > 0, "mini_batch / max_fan_out must be positive");
   AMMSB_CHECK_ARG(ctx, c.mb_candidates >= c.mini_batch && c.mb_candidates % 256 == 0, "bad candidate capacity");
+  AMMSB_CHECK_ARG(ctx, c.max_nodes >= c.mini_batch + 1 && c.max_nodes >= c.max_fan_out + 1 && c.max_edges >= c.mini_batch &&
+                           c.max_edges >= c.max_fan_out,
+                  "max_nodes / max_edges smaller than the largest mini-batch (sample.cc:129-131)");
   AMMSB_HIP(ctx, hipSetDevice(ctx->device));
   ammsb_loop* lp = new (std::nothrow) ammsb_loop();
   if (!lp) return AMMSB_ENOMEM;
@@ -242,6 +260,7 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
   lp->c.heldout_set = lp->has_heldout ? &lp->heldout : nullptr;
   lp->link_edges_cap = c.max_fan_out;
   lp->link_nodes_cap = c.max_fan_out + 1;
+  lp->n_nbr = ctx->params.num_node_sample;
   lp->w_link = static_cast<float>(ctx->params.N);                                                    // sample.cc:268
   lp->w_nonlink = static_cast<float>(2 * ctx->params.E) / static_cast<float>(c.mini_batch);          // sample.cc:292
 #define CREATE_HIP(call)                                                                           \
@@ -255,21 +274,35 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
   } while (0)
   CREATE_HIP(hipStreamCreateWithFlags(&lp->main, hipStreamNonBlocking));
   CREATE_HIP(hipStreamCreateWithFlags(&lp->side, hipStreamNonBlocking));
-  for (hipEvent_t* ev : {&lp->ev_in, &lp->ev_out, &lp->ev_prime, &lp->ev_main[0], &lp->ev_main[1], &lp->ev_samp[0],
-                         &lp->ev_samp[1]})
+  for (hipEvent_t* ev : {&lp->ev_in, &lp->ev_out, &lp->ev_prime, &lp->ev_first, &lp->ev_main[0], &lp->ev_main[1],
+                         &lp->ev_main[2], &lp->ev_samp[0], &lp->ev_samp[1], &lp->ev_samp[2]})
     CREATE_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-  lp->serial = (c.flags & AMMSB_LOOP_SERIAL) != 0;
-  // one device allocation: ring [CHUNK + 2], cur[2], nxt[2], cursor
-  const size_t n_desc = CHUNK + 2 + 4;
+  // the caller's two Sample buffers and a third set of the same sizes (zeroed: whatever a kernel reads is a valid id)
+  for (int i = 0; i < 2; ++i) lp->buf[i] = SampleBuf{c.edges[i], c.nodes[i], c.neighbors[i], c.nbr_table[i]};
+  {
+    const size_t e_b = align256(sizeof(uint64_t) * c.max_edges), n_b = align256(sizeof(uint32_t) * c.max_nodes);
+    const size_t p_b = align256(sizeof(uint32_t) * (size_t)c.max_nodes * lp->n_nbr);
+    const size_t t_b = align256(sizeof(uint32_t) * (size_t)c.max_nodes * 2 * lp->n_nbr);
+    CREATE_HIP(hipMalloc(&lp->own_mem, e_b + n_b + p_b + t_b));
+    CREATE_HIP(hipMemset(lp->own_mem, 0, e_b + n_b + p_b + t_b));
+    char* p = static_cast<char*>(lp->own_mem);
+    lp->buf[2].edges = reinterpret_cast<uint64_t*>(p);
+    lp->buf[2].nodes = reinterpret_cast<uint32_t*>(p + e_b);
+    lp->buf[2].neighbors = reinterpret_cast<uint32_t*>(p + e_b + n_b);
+    lp->buf[2].nbr_table = reinterpret_cast<uint32_t*>(p + e_b + n_b + p_b);
+  }
+  // one device allocation: ring [CHUNK + 4], cur[2], nxt[3], cursor
+  const size_t n_desc = CHUNK + 4 + 5;
   CREATE_HIP(hipMalloc(&lp->d_ring, sizeof(ammsb_step_desc) * n_desc + 64));
   CREATE_HIP(hipMemset(lp->d_ring, 0, sizeof(ammsb_step_desc) * n_desc + 64));
-  lp->d_cur[0] = lp->d_ring + CHUNK + 2;
-  lp->d_cur[1] = lp->d_ring + CHUNK + 3;
-  lp->d_nxt[0] = lp->d_ring + CHUNK + 4;
-  lp->d_nxt[1] = lp->d_ring + CHUNK + 5;
+  lp->d_cur[0] = lp->d_ring + CHUNK + 4;
+  lp->d_cur[1] = lp->d_ring + CHUNK + 5;
+  lp->d_nxt[0] = lp->d_ring + CHUNK + 6;
+  lp->d_nxt[1] = lp->d_ring + CHUNK + 7;
+  lp->d_nxt[2] = lp->d_ring + CHUNK + 8;
   lp->d_cursor = reinterpret_cast<uint32_t*>(lp->d_ring + n_desc);
   for (Stage& st : lp->stage) {
-    CREATE_HIP(hipHostMalloc(&st.ring, sizeof(ammsb_step_desc) * (CHUNK + 2), hipHostMallocDefault));
+    CREATE_HIP(hipHostMalloc(&st.ring, sizeof(ammsb_step_desc) * (CHUNK + 4), hipHostMallocDefault));
     CREATE_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
     st.used = false;
   }
@@ -279,16 +312,11 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     CREATE_HIP(hipDeviceGetAttribute(&lp->wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
   }
 #undef CREATE_HIP
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b)
-      for (int p = 0; p < 2; ++p) {
-        int rc = AMMSB_OK;
-        if (lp->serial) {
-          rc = capture(lp, 0, a, b, p, &lp->exec[a][b][p]);
-        } else if (b == 0) {
-          rc = capture(lp, 1, a, 0, p, &lp->exec_main[a][p]);
-          if (rc == AMMSB_OK) rc = capture(lp, 2, 0, a, p, &lp->exec_samp[a][p]);
-        }
+  for (int link = 0; link < 2; ++link)
+    for (int b = 0; b < NBUF; ++b)
+      for (int dp = 0; dp < 2; ++dp) {
+        int rc = capture(lp, 1, link, b, dp, &lp->exec_main[link][b][dp]);
+        if (rc == AMMSB_OK) rc = capture(lp, 2, link, b, dp, &lp->exec_samp[link][b][dp]);
         if (rc != AMMSB_OK) {
           destroy(lp);
           return rc;
@@ -313,49 +341,69 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
   LOOP_RC(check_choice(lp, *pending));
   for (uint32_t i = 0; i < n_steps; ++i) LOOP_RC(check_choice(lp, next[i]));
   hipStream_t s = as_stream(stream);
+  const uint32_t p0 = parity;
+  // mini-batch j of this call (j = 0: the pending one; j >= 1: next[j - 1], consumed by step j) lives in buffer set
+  // (p0 + j) % 3 and was / is sampled with the neighbour-sampler streams of Sample[(p0 + j) % 2]
+  auto choice = [&](uint32_t j) -> const ammsb_mb_choice& { return j == 0 ? *pending : next[j - 1]; };
   LOOP_HIP(lp, hipEventRecord(lp->ev_in, s));
   LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_in, 0));
   uint32_t done = 0;
-  int p = static_cast<int>(parity);
   while (done < n_steps) {
     const uint32_t cnt = n_steps - done < CHUNK ? n_steps - done : CHUNK;
     Stage& st = lp->stage[lp->next_stage];
     lp->next_stage ^= 1;
     if (st.used) LOOP_HIP(lp, hipEventSynchronize(st.done));  // the upload two chunks ago has long executed
-    // ring[i] = descriptor of step done + i (i = 0 .. cnt; entry cnt is only the last step's look-ahead)
-    for (uint32_t i = 0; i <= cnt; ++i) {
-      const ammsb_mb_choice& ch = (done + i == 0) ? *pending : next[done + i - 1];
-      st.ring[i] = make_desc(lp, ch, first_step_count + done + i);
+    // ring[i] = descriptor of mini-batch done + i as step done + i (entries past the call's last batch repeat it:
+    // they are handed over by the last steps' kernels and never used)
+    for (uint32_t i = 0; i < cnt + 4; ++i) {
+      const uint32_t j = done + i <= n_steps ? done + i : n_steps;
+      st.ring[i] = make_desc(lp, choice(j), first_step_count + done + i);
     }
-    st.ring[cnt + 1] = st.ring[cnt];  // read by the last advance, never used
-    LOOP_HIP(lp, hipMemcpyAsync(lp->d_ring, st.ring, sizeof(ammsb_step_desc) * (cnt + 2), hipMemcpyHostToDevice, lp->main));
+    LOOP_HIP(lp, hipMemcpyAsync(lp->d_ring, st.ring, sizeof(ammsb_step_desc) * (cnt + 4), hipMemcpyHostToDevice, lp->main));
     LOOP_HIP(lp, hipEventRecord(st.done, lp->main));
     st.used = true;
-    loop_prime_kernel<<<1, 1, 0, lp->main>>>(lp->d_ring, lp->d_cursor, lp->d_cur[p], lp->d_nxt[p]);
+    const int dp0 = (int)((p0 + done) & 1u);
+    loop_prime_kernel<<<1, 1, 0, lp->main>>>(lp->d_ring, lp->d_cursor, lp->d_cur[dp0], lp->d_nxt[(p0 + done + 2) % NBUF]);
     LOOP_HIP(lp, hipGetLastError());
-    if (!lp->serial) LOOP_HIP(lp, hipEventRecord(lp->ev_prime, lp->main));
+    LOOP_HIP(lp, hipEventRecord(lp->ev_prime, lp->main));
+    if (done == 0) {
+      // ramp-up: mini-batch 1 is sampled before step 0 starts (eagerly, straight from its ring entry); from then on
+      // the sampler chain of step i produces mini-batch i + 2
+      LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
+      LOOP_RC(record_sampler(lp, choice(1).link ? 1 : 0, (int)((p0 + 1) % NBUF), (int)((p0 + 1) & 1u), lp->d_ring + 1, lp->side));
+      LOOP_HIP(lp, hipEventRecord(lp->ev_first, lp->side));
+    }
     for (uint32_t i = 0; i < cnt; ++i) {
-      const int cl = st.ring[i].link ? 1 : 0, nl = st.ring[i + 1].link ? 1 : 0;
-      if (lp->serial) {
-        LOOP_HIP(lp, hipGraphLaunch(lp->exec[cl][nl][p], lp->main));
-      } else {
-        const uint32_t gi = done + i;  // step index within this call
-        // sampler of the mini-batch for step gi + 1: reads the descriptors the previous step's theta kernel handed
-        // over (or the prime kernel wrote) and overwrites the buffer pair that step read
-        LOOP_HIP(lp, hipStreamWaitEvent(lp->side, i == 0 ? lp->ev_prime : lp->ev_main[(gi - 1) & 1], 0));
-        LOOP_HIP(lp, hipGraphLaunch(lp->exec_samp[nl][p], lp->side));
-        LOOP_HIP(lp, hipEventRecord(lp->ev_samp[gi & 1], lp->side));
-        // main chain of step gi: its mini-batch was sampled during step gi - 1
-        if (gi > 0) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(gi - 1) & 1], 0));
-        LOOP_HIP(lp, hipGraphLaunch(lp->exec_main[cl][p], lp->main));
-        LOOP_HIP(lp, hipEventRecord(lp->ev_main[gi & 1], lp->main));
+      const uint32_t gi = done + i;  // step index within this call
+      const int dp = (int)((p0 + gi) & 1u);
+      if (gi + 2 <= n_steps) {  // the call ends with exactly ONE pending mini-batch (n_steps), like the eager loop
+        // reads the descriptor the previous step's last kernel (or the prime kernel) handed over, overwrites the
+        // buffer set step gi - 1 read
+        LOOP_HIP(lp, hipStreamWaitEvent(lp->side, i == 0 ? lp->ev_prime : lp->ev_main[(gi - 1) % NBUF], 0));
+        LOOP_HIP(lp, hipGraphLaunch(lp->exec_samp[choice(gi + 2).link ? 1 : 0][(p0 + gi + 2) % NBUF][dp], lp->side));
+        LOOP_HIP(lp, hipEventRecord(lp->ev_samp[gi % NBUF], lp->side));
       }
-      p ^= 1;
+      // main chain of step gi: its mini-batch was sampled during step gi - 2 (gi = 1: by the ramp-up above)
+      if (gi == 1) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_first, 0));
+      if (gi >= 2) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(gi - 2) % NBUF], 0));
+      LOOP_HIP(lp, hipGraphLaunch(lp->exec_main[choice(gi).link ? 1 : 0][(p0 + gi) % NBUF][dp], lp->main));
+      LOOP_HIP(lp, hipEventRecord(lp->ev_main[gi % NBUF], lp->main));
     }
     lp->graphs_launched += cnt;
     done += cnt;
   }
-  if (!lp->serial) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(n_steps - 1) & 1], 0));  // the pending sample
+  // the pending mini-batch (n_steps): wait for its sampler, then move it into the caller's Sample[(p0 + n) % 2]
+  LOOP_HIP(lp, hipStreamWaitEvent(lp->main, n_steps == 1 ? lp->ev_first : lp->ev_samp[(n_steps - 2) % NBUF], 0));
+  const uint32_t from = (p0 + n_steps) % NBUF, to = (p0 + n_steps) & 1u;
+  if (from != to) {
+    const ammsb_mb_choice& ch = choice(n_steps);
+    const size_t ne = ch.link ? ch.n : lp->c.mini_batch, nv = ne + 1;
+    const SampleBuf &a = lp->buf[from], &b = lp->buf[to];
+    LOOP_HIP(lp, hipMemcpyAsync(b.edges, a.edges, sizeof(uint64_t) * ne, hipMemcpyDeviceToDevice, lp->main));
+    LOOP_HIP(lp, hipMemcpyAsync(b.nodes, a.nodes, sizeof(uint32_t) * nv, hipMemcpyDeviceToDevice, lp->main));
+    LOOP_HIP(lp, hipMemcpyAsync(b.neighbors, a.neighbors, sizeof(uint32_t) * nv * lp->n_nbr, hipMemcpyDeviceToDevice, lp->main));
+    LOOP_HIP(lp, hipMemcpyAsync(b.nbr_table, a.nbr_table, sizeof(uint32_t) * nv * 2 * lp->n_nbr, hipMemcpyDeviceToDevice, lp->main));
+  }
   LOOP_HIP(lp, hipEventRecord(lp->ev_out, lp->main));
   LOOP_HIP(lp, hipStreamWaitEvent(s, lp->ev_out, 0));
   return AMMSB_OK;

@@ -30,7 +30,8 @@ struct ammsb_step_advance {
   const ammsb_step_desc* ring;  // device ring of upcoming descriptors
   uint32_t* cursor;             // index of the CURRENT step's descriptor in ring
   ammsb_step_desc* cur_out;     // <- ring[cursor + 1]
-  ammsb_step_desc* nxt_out;     // <- ring[cursor + 2]
+  ammsb_step_desc* nxt_out;     // <- ring[cursor + nxt_offset]: the batch the next step's sampler chain produces
+  uint32_t nxt_offset;
 };
 
 // ---- descriptor forms (same checks and dispatch as the extern "C" functions; `cap` sizes the grid)

@@ -184,6 +184,8 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
     lc.mb_count = mb_count_->data();
     lc.mini_batch = static_cast<uint32_t>(cfg_.mini_batch_size);
     lc.max_fan_out = static_cast<uint32_t>(cfg_.trainingGraph->MaxFanOut());
+    lc.max_nodes = static_cast<uint32_t>(samples_[0]->dev_nodes.Count());
+    lc.max_edges = static_cast<uint32_t>(samples_[0]->dev_edges.Count());
     lc.flags = 0;
     queue_.Finish();
     ThrowIfError(ctx_.get(), ammsb_loop_create(ctx_.get(), &lc, &loop_), "ammsb_loop_create");

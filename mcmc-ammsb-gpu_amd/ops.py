@@ -644,7 +644,9 @@ class GraphLoop:
         cfg.mb_seeds, cfg.mb_candidates = sampler.rand.seeds.data_ptr(), sampler.C
         cfg.mb_workspace, cfg.mb_count = sampler.workspace.data_ptr(), sampler.count.data_ptr()
         cfg.mini_batch, cfg.max_fan_out = sampler.m, sampler.max_fan_out
-        cfg.flags = (_capi.LOOP_TIMESTAMPS if timestamps else 0) | (2 if os.environ.get("AMMSB_LOOP_SERIAL") else 0)
+        cfg.max_nodes = min(int(s.dev_nodes.numel()) for s in samples)
+        cfg.max_edges = min(int(s.dev_edges.numel()) for s in samples)
+        cfg.flags = _capi.LOOP_TIMESTAMPS if timestamps else 0
         self.timestamps_on = bool(timestamps)
         self._keep = (theta, beta, pi, phi_sum, training_set, heldout_set, phi, beta_upd, samples, sampler)
         self._h = C.c_void_p()

@@ -238,7 +238,13 @@ def test_pi_init_gamma(orc, hip, N, K, rib):
 
 
 @pytest.mark.parametrize("N,n,wg,n_nodes", [(12000, 20, 32, 65536), (1000, 32, 64, 100), (5000, 8, 32, 70001),
-                                             (5000, 200, 32, 300)])  # n = 200: table too large for LDS -> global-table kernel
+                                             (5000, 200, 32, 300),  # n = 200: table too large for LDS -> global-table kernel
+                                             # n = 32: the wave-per-stream kernel
+                                             (100000, 32, 32, 65537),   # more nodes than streams: some streams take two
+                                             (1000000, 32, 32, 8193),
+                                             (40, 32, 32, 300),         # N barely above n: most draws are rejected,
+                                             (34, 32, 16, 50),          # several batches of raw draws per node
+                                             (1000, 32, 1024, 3000)])
 def test_neighbor_sampler(orc, hip, N, n, wg, n_nodes):
     # wg-sample-test.cc:22-72 shape (N=12000, n=20, 64k samples) + bit-exactness vs the oracle
     import torch
