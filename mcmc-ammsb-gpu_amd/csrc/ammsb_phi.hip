@@ -903,6 +903,7 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
           if (ring == 2) return launch_phi_lds<4, 1, 2>(ctx, a, n_groups, s);
           if (ring == 4) return launch_phi_lds<4, 1, 4>(ctx, a, n_groups, s);
           if (ring == 8 || (a.n & 1)) return launch_phi_lds<4, 1, 8>(ctx, a, n_groups, s);
+          if (ring == 42) return launch_phi_lds2<4, 4, 2>(ctx, a, n_groups, s);  // A/B: two rows, four slots
           if (ring == 22 || (a.n & 3)) return launch_phi_lds2<4, 8, 2>(ctx, a, n_groups, s);  // two rows per iteration
           return launch_phi_lds2<4, 8, 4>(ctx, a, n_groups, s);                               // four (n % 4 == 0)
         case 8:
