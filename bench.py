@@ -150,17 +150,22 @@ def cpu_baseline(args, lrn, cfg, ds, n_nodes_big):
     t1 = run(s1, 1)
     sN = args.cpu_sample or int(min(n_nodes_big - 1, max(64, 8.0 * cores / per_item)))
     tN = run(sN, cores)
+    reps = 1
+    while tN < 6.0 and reps < 64 and not args.cpu_sample:  # a whole mini-batch is too short on this box: repeat it
+        tN += run(sN, cores)
+        reps += 1
+    sN_total = sN * reps
     elems = (n + 1) * K  # pi elements read per mini-batch node in update_phi
-    return {"value": sN / tN, "unit": "mini-batch edges/s", "cores": int(cores), "kind": "port",
+    return {"value": sN_total / tN, "unit": "mini-batch edges/s", "cores": int(cores), "kind": "port",
             "one_thread_value": s1 / t1, "cpu_model": info["model"], "nproc": info["nproc"],
             "affinity": info["affinity"], "cgroup_cpu_quota": info["cgroup_cpu_quota"],
             "omp": "OMP threads = CPUs usable by this process (min of affinity and cgroup quota), no explicit binding "
                    "(OMP_PROC_BIND unset), schedule(dynamic) over nodes / edges",
             "ns_per_pi_element_one_thread": round(t1 / (s1 * elems) * 1e9, 2),
-            "sample": "%d of the %d nodes and %d of the %d edges of one non-link mini-batch on %d threads in %.1f s "
+            "sample": "%d x (%d of the %d nodes and %d of the %d edges of one non-link mini-batch) on %d threads in %.1f s "
                       "(phi+pi+beta, the reference's per-thread CPU kernels restated in oracle/, -O3 -march=native "
                       "-ffp-contract=off); one thread: %d nodes+edges in %.1f s"
-                      % (sN, n_nodes_big, sN, cfg.mini_batch_size, cores, tN, s1, t1)}
+                      % (reps, sN, n_nodes_big, sN, cfg.mini_batch_size, cores, tN, s1, t1)}
 
 
 def cpp_dropin(args, hostlib, N, K, m, n, wg, edges, note):

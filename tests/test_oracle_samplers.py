@@ -87,3 +87,18 @@ def test_host_sample_reports_overflow_instead_of_writing(dataset):
                                   C.byref(ne), v, v.size, C.byref(nv), C.byref(w))
     assert rc == -2 and ne.value == 256 and nv.value >= 256
     assert not e.any() and not v.any()   # nothing was copied
+
+
+def test_golden_host_sampler_vectors(orc):
+    """tests/golden/host_samplers.npz (made by the oracle, see make_golden_samplers.py): today's oracle build -- on
+    whatever glibc / libstdc++ this host has -- reproduces every vector (edges, node order, weight, rand_r seed) bit
+    for bit.  test_host_samplers_match_the_oracle ties the product's host library to the same oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgs", os.path.join(HERE, "golden", "make_golden_samplers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(HERE, "golden", "host_samplers.npz"))
+    now = mod.compute()
+    assert set(now) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(g[k], now[k]), k
