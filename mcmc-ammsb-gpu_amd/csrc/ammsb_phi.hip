@@ -48,9 +48,13 @@ struct PhiArgs {
 // Device wall-clock stamps without extra launches: block 0 of update_phi notes when it starts (slot 0), block 0 of
 // update_pi -- the next kernel on the stream -- when IT starts (slot 1).  The difference is update_phi's duration
 // plus one kernel boundary: a slight over-estimate, never an under-estimate.
+// (not inlined on purpose: inlined at the top of update_phi_lds_kernel<16, 1> it cost the K = 1024 kernel two spilled
+// registers -- 8 bytes of scratch per lane -- for a store one thread of one block makes)
+__device__ __noinline__ void note_stamp_slow(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
+  if (desc && blockIdx.x == 0 && threadIdx.x == 0) stamps[2 * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
+}
 __device__ __forceinline__ void note_stamp(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
-  if (stamps && desc && blockIdx.x == 0 && threadIdx.x == 0)
-    stamps[2 * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
+  if (stamps) note_stamp_slow(stamps, desc, which);  // wave-uniform: a call only when time stamps are on
 }
 
 // the per-iteration scalars, from the descriptor when there is one (block-uniform scalar loads)
@@ -285,8 +289,13 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // D = ring depth (power of two): rows q+1 .. q+D-1 are in flight while row q is reduced.  Two slots are right for
 // 4 KiB rows (K = 1024: LDS, not latency, limits the waves per CU); short rows (K = 256: one 1 KiB piece per
 // row) need more rows in flight per wave to keep enough bytes on their way to each CU.
-template <int KPT, int W, int D = 2>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 4 ? AMMSB_PHI_WPE4 : KPT <= 8 ? AMMSB_PHI_WPE8 : KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
+// NB = nodes per block (only with W == 1): NB independent one-wave nodes share the block's ziggurat tables, nothing
+// else -- 2 x (3 x 4 KiB + 128 B) + 1.5 KiB = 26 368 B puts six such blocks = TWELVE waves on a CU where the one-node
+// block (13 956 B) fits eleven times.  The waves never wait for each other after the table load (wave-local LDS
+// ordering instead of block barriers: their node counts may differ).
+template <int KPT, int W, int D = 2, int NB = 1>
+__global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT <= 4 ? AMMSB_PHI_WPE4 : KPT <= 8 ? AMMSB_PHI_WPE8 : KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
+  static_assert(NB == 1 || W == 1, "several nodes per block only for one-wave nodes");
   // L = 64 W lanes per node: wave wv owns columns 64 wv + ln + L j, i.e. KPT chunks of 64 consecutive floats per
   // row.  Each wave runs the single-wave pipeline on its own slice (own ring, own waits); the only cross-wave
   // step is the WG_SUM of a neighbour's probs: one LDS exchange and one barrier per row.
@@ -298,19 +307,39 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 4
   extern __shared__ __align__(16) char smem[];  // per wave: [D][KW] ring, [KW] normals; then [n] u32 (id | link bit)
   __shared__ ZigTables zig;
   __shared__ float xsum[W > 1 ? 2 * L : 1];  // double-buffered lane partials of the cross-wave sum
-  const int tid = threadIdx.x, wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
-  char* wave_smem = smem + wv * ((D + 1) * KW * sizeof(float));
+  // tid = thread within its node's group of 64 W lanes; nb = which of the block's NB nodes
+  const int tid = NB == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63), nb = NB == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const int wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
+  const uint32_t n = a.n;
+  char* node_smem = smem;
+  if constexpr (NB > 1) node_smem += nb * (W * (D + 1) * KW * sizeof(float) + ((n * sizeof(uint32_t) + 15) & ~15u));
+  char* wave_smem = node_smem + wv * ((D + 1) * KW * sizeof(float));
   float* ring = reinterpret_cast<float*>(wave_smem);
   float* s_noise = ring + D * KW;
-  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + W * (D + 1) * KW * sizeof(float));
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(node_smem + W * (D + 1) * KW * sizeof(float));
+  // orders this node's LDS traffic: a block barrier for one node per block; with several independent one-wave nodes a
+  // wave-local wait (one wave's LDS operations complete in order)
+  auto group_sync = [&]() {
+    if constexpr (NB == 1) {
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
 
   const PhiStep st = phi_step(a);
   note_stamp(a.stamps, a.desc, 0);
-  const uint32_t g = a.group_begin + blockIdx.x;
-  if (g >= st.group_end) return;  // block-uniform
-  const uint32_t n = a.n;
+  if constexpr (NB > 1) {  // every wave of the block helps loading the shared tables before any of them may leave
+    if (a.noise_on) zig_load(&zig);
+    __syncthreads();
+  }
+  const uint32_t g = a.group_begin + blockIdx.x * NB + nb;
+  if (g >= st.group_end) return;  // uniform per node group
   const float EPS = a.epsilon;
-  if (a.noise_on) zig_load(&zig);
+  if constexpr (NB == 1) {
+    if (a.noise_on) zig_load(&zig);
+  }
 
   constexpr int HP = KPT / 2;  // column pairs per lane: pair p = columns tid + L (2p), tid + L (2p + 1)
   f32x2 bf[HP];
@@ -362,13 +391,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(KPT <= 4
 
   for (uint64_t i = g; i < st.n_nodes; i += st.G) {
     const uint32_t node = a.nodes[i];
-    __syncthreads();  // orders the LDS traffic of consecutive nodes
+    group_sync();  // orders the LDS traffic of consecutive nodes
     for (uint32_t q = tid; q < n; q += L) {
-      const uint32_t nb = a.neighbors[i * n + q];
-      const bool y = set_has(a.set, make_edge(node, nb));
-      s_nb[q] = nb | (y ? 0x80000000u : 0u);
+      const uint32_t nbq = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nbq));
+      s_nb[q] = nbq | (y ? 0x80000000u : 0u);
     }
-    __syncthreads();
+    group_sync();
 
     const float phi_sum = a.phi_sum[node];
     const float inv_phi_sum = 1.0f / phi_sum;
@@ -737,10 +766,10 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
   return AMMSB_OK;
 }
 
-template <int KPT, int W, int D = 2>
+template <int KPT, int W, int D = 2, int NB = 1>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
-  const size_t lds = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
-  update_phi_lds_kernel<KPT, W, D><<<n_groups, 64 * W, lds, s>>>(a);
+  const size_t per_node = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + ((sizeof(uint32_t) * a.n + 15) & ~(size_t)15);
+  update_phi_lds_kernel<KPT, W, D, NB><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -910,7 +939,14 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
           if (ring == 2) return launch_phi_lds<8, 1, 2>(ctx, a, n_groups, s);
           if (ring == 4 || (a.n & 1)) return launch_phi_lds<8, 1, 4>(ctx, a, n_groups, s);
           return launch_phi_lds2<8, 4, 2>(ctx, a, n_groups, s);
-        case 16: return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
+        case 16: {
+          static const int nb = [] {  // AMMSB_PHI_NB=1|2: nodes per block of the K = 1024 kernel (A/B runs)
+            const char* f = getenv("AMMSB_PHI_NB");
+            return f ? atoi(f) : 1;
+          }();
+          if (nb == 2) return launch_phi_lds<16, 1, 2, 2>(ctx, a, n_groups, s);
+          return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
+        }
         case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);
       }
     } else if (kpt == 8 && wg == 128) {
