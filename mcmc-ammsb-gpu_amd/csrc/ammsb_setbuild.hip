@@ -39,11 +39,16 @@ __global__ __launch_bounds__(256) void set_build_kernel(const uint64_t* keys, ui
       const int bb = bucket ^ b;
       unsigned long long* bin = slots + (bb * bins + bin_of(cur, bb, prime_idx, bins)) * 4;
       for (int s = 0; s < 4; ++s) {
+        // a plain load may be stale (this CU's L1 is not refreshed by anybody's atomics, its own included): fine as a
+        // hint for "is this slot worth a CAS" -- slots only ever go from empty to taken -- but NOT as proof that the
+        // key in hand is already a member: a displaced key WAS in the slot it was just swapped out of, and the L1 line
+        // this thread loaded before the swap still says so.  Only the thread's own, never yet placed key (walk == 0)
+        // may meet a copy of itself (a duplicate in the input).
         const unsigned long long seen = bin[s];
-        if (seen == cur) return;  // duplicate key in the input: already a member
+        if (walk == 0 && seen == cur) return;
         if (seen == kEmpty) {
           const unsigned long long old = atomicCAS(&bin[s], kEmpty, cur);
-          if (old == kEmpty || old == cur) return;
+          if (old == kEmpty || (walk == 0 && old == cur)) return;
         }
       }
     }
