@@ -80,6 +80,9 @@ struct Config {
   // new: with async_launch + device_sampling, enqueue whole iterations as captured hipGraphs (ammsb_loop,
   // include/ammsb.h): one hipGraphLaunch per iteration instead of a dozen kernel launches.  Results are identical.
   bool graph_launch;
+  // new: multi-GPU.  Non-null with world() > 1 => mcmc::Learner shards every iteration over the ranks (one process
+  // per GPU, same Config and data on every rank) and exchanges through it (include/mcmc/exchange.h).
+  std::shared_ptr<class Exchange> exchange;
   ulong2 device_sampling_seed;  // new: streams of the device sampler's candidate draws
   uint64_t device_sampling_host_seed;  // new: host generator choosing (link?, u) per mini-batch
   // new: rand_r seeds of the two Sample buffers.  The reference takes them from the process-global

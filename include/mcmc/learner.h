@@ -49,6 +49,14 @@ class Learner {
   uint32_t CandidatesFor(uint64_t u);  // candidate draws of a non-link mini-batch of vertex u
   uint32_t CandidatesForExcluded(uint32_t excluded);
   void CheckDeviceSampler();           // throws if a mini-batch came up short since the last check
+  // multi-GPU (Config::exchange with world() > 1; new, see include/mcmc/exchange.h): every rank runs the same
+  // learner on the same data and seeds, computes its block of update_phi's virtual groups / its slice of the
+  // gradient's and the perplexity's edges, and exchanges phi_vec rows, [2K] gradient partials and the 4 sums.
+  bool Sharded() const;
+  void Step(Sample& s, Float weight);  // phi, pi, beta of one iteration (sharded or not)
+  void StepSharded(Sample& s, Float weight);
+  Float Perplexity(PerplexityCalculator* calc);
+  void GatherShardedState();  // before a checkpoint: owners hand out their phi streams and running means
 
   const Config& cfg_;
   clcuda::Queue queue_;
@@ -94,6 +102,9 @@ class Learner {
   Float weights_[2] = {0, 0};
   ammsb_mb_choice choice_[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // what sits in each sample's buffers (device sampling)
   ammsb_loop* loop_ = nullptr;
+  uint32_t cc_ = 0;  // virtual groups per rank block: rank r owns [r * cc_, (r + 1) * cc_)
+  std::unique_ptr<clcuda::Buffer<Float>> all_grads_, grads_sum_, tail_buf_;
+  std::unique_ptr<clcuda::Buffer<ammsb_ppx_sums>> all_sums_;
   std::unique_ptr<Sample> samples_[2];  // MCMC_SAMPLE_PARALLEL (CMakeLists.txt:42, default ON)
   std::future<Float> futures_[2];
   int phase_;

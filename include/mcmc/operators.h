@@ -173,6 +173,13 @@ class PhiUpdater {
   uint64_t UpdatePhiTime() const { return t_update_phi_; }  // ns of device time (hip events)
   uint64_t UpdatePiTime() const { return t_update_pi_; }
   clcuda::Buffer<Float>& GetPhiVec() { return phi_vec_; }
+  // the two halves of operator() for a sharding caller (mcmc::Learner with an Exchange): BeginCall() counts the
+  // iteration (phi.cc:739), UpdatePhi enqueues the virtual groups [group_begin, group_end) only, UpdatePi applies
+  // phi_vec rows [0, n) once they are complete everywhere.  Enqueue-only: the caller synchronises.
+  void BeginCall() { ++count_calls_; }
+  void UpdatePhi(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex>& neighbors, uint32_t n, uint32_t group_begin,
+                 uint32_t group_end);
+  void UpdatePi(clcuda::Buffer<Vertex>& nodes, uint32_t n);
   random::OpenClRandom& Rand() { return rand_; }  // for the captured-graph loop (ammsb_loop)
   uint32_t& CountCalls() { return count_calls_; }
   uint32_t Local() const { return local_; }
@@ -204,6 +211,11 @@ class BetaUpdater {
   void operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale);
   clcuda::Buffer<Float>& GetGrads() { return grads_; }
   clcuda::Buffer<Float>& GetThetaSum();  // beta.h:27: as of the last operator()
+  // halves of operator() for a sharding caller: the gradient over edges [edge_begin, edge_end) into `out` ([2K]),
+  // then the theta / beta step from an externally reduced gradient.  Enqueue-only.
+  void BeginCall() { ++count_calls_; }
+  void CalculateGrads(clcuda::Buffer<Edge>* edges, uint32_t num_edges, uint32_t edge_begin, uint32_t edge_end, Float* out);
+  void UpdateTheta(Float scale, const Float* grads);
   random::OpenClRandom& Rand() { return rand_; }  // for the captured-graph loop (ammsb_loop)
   uint32_t& CountCalls() { return count_calls_; }
   uint32_t Local() const { return local_; }
@@ -239,6 +251,12 @@ class PerplexityCalculator {
                        RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Edge>& edges, OpenClSet* edgeSet,
                        const std::vector<std::string>& compileFlags = {}, const std::string& baseFuncs = "");
   Float operator()();  // returns -average log-likelihood (perplexity.cc:273)
+  // for a sharding caller: BeginCall() counts the evaluation (perplexity.cc:252), Partial enqueues edges
+  // [edge_begin, edge_end) and returns the DEVICE sums record of this calculator (valid once the stream is drained)
+  void BeginCall() { ++count_calls_; }
+  ammsb_ppx_sums* Partial(uint32_t edge_begin, uint32_t edge_end);
+  uint32_t NumEdges() { return static_cast<uint32_t>(edges_.Count()); }
+  clcuda::Buffer<Float>& PerEdge() { return ppx_per_edge_; }  // the running means, indexed by edge position
   uint64_t PerplexityTime() const { return t_ppx_; }  // ns; the four reductions are inside the same launch
   uint64_t AccumulateTime() const { return 0; }
   bool Serialize(std::ostream* out);  // perplexity.cc:276-293

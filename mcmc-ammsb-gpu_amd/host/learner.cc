@@ -3,6 +3,7 @@
 // std::mt19937(6342455113) + std::gamma_distribution, pi_0 from the device gamma streams {11,113}),
 // same loop: join the sample produced in the background, start the next one, phi, pi, beta.
 #include "mcmc/learner.h"
+#include "mcmc/exchange.h"
 #include "mcmc/serialize.h"
 
 #include <hip/hip_runtime.h>
@@ -143,6 +144,18 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
     hipEvent_t e;
     clcuda::Check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     ev_sampler_ = e;
+  }
+  if (Sharded()) {
+    if (cfg_.graph_launch) throw std::runtime_error("graph_launch is single-rank (the exchange is not captured)");
+    if (!ctx_) ctx_ = AcquireContext(cfg_, queue_);
+    const uint32_t R = static_cast<uint32_t>(cfg_.exchange->world());
+    cc_ = (AMMSB_MAX_GROUPS + R - 1) / R;
+    const uint64_t max_nodes = samples_[0]->dev_nodes.Count();
+    all_grads_.reset(new clcuda::Buffer<Float>(queue_.GetContext(), static_cast<uint64_t>(R) * 2 * cfg_.K));
+    grads_sum_.reset(new clcuda::Buffer<Float>(queue_.GetContext(), 2 * cfg_.K));
+    tail_buf_.reset(new clcuda::Buffer<Float>(
+        queue_.GetContext(), std::max<uint64_t>(max_nodes > AMMSB_MAX_GROUPS ? max_nodes - AMMSB_MAX_GROUPS : 0, 1) * cfg_.K));
+    all_sums_.reset(new clcuda::Buffer<ammsb_ppx_sums>(queue_.GetContext(), R));
   }
   std::mt19937 mt19937(6342455113);  // learner.cc:150-153
   std::gamma_distribution<Float> gamma_distribution(cfg_.eta0, cfg_.eta1);
@@ -309,17 +322,124 @@ Float Learner::DoSample(Sample* sample) {
   return weight;
 }
 
+bool Learner::Sharded() const { return cfg_.exchange && cfg_.exchange->world() > 1; }
+
+void Learner::Step(Sample& s, Float weight) {
+  if (Sharded()) return StepSharded(s, weight);
+  phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), s.num_nodes);
+  betaUpdater_(&s.dev_edges, s.num_edges, weight);
+}
+
+// One iteration over `world` ranks.  Ownership is fixed (rank r: groups [r cc, (r+1) cc)) because a group's RNG
+// streams advance only where the group runs; phi_vec row i < G belongs to group i, row G + t to group t (its second
+// node).  The in-place all-gather region is rows [0, world * cc), which can reach past G: owners park their tail rows
+// first and hand them out afterwards.  A launch whose groups all sit in rank 0's block (a link mini-batch of a
+// low-degree vertex) is a broadcast.  pi is bit-identical to a single rank's; theta differs by the association of the
+// gradient sum (per-rank partials summed in rank order).
+void Learner::StepSharded(Sample& s, Float weight) {
+  Exchange& x = *cfg_.exchange;
+  const uint32_t R = static_cast<uint32_t>(x.world()), r = static_cast<uint32_t>(x.rank()), Cc = cc_;
+  const uint32_t n = s.num_nodes, K = static_cast<uint32_t>(cfg_.K);
+  hipStream_t stream = static_cast<hipStream_t>(queue_.stream());
+  clcuda::Buffer<Vertex>& nbrs = s.neighbor_sampler.GetData();
+  Float* pv = phiUpdater_.GetPhiVec().data();
+  Float* tb = tail_buf_->data();
+  const size_t row = static_cast<size_t>(K) * sizeof(Float);
+  if (n == 0) throw std::runtime_error("mini-batch nodes size = 0!");  // phi.cc:732
+  phiUpdater_.BeginCall();
+  const uint32_t G = std::min<uint32_t>(n, AMMSB_MAX_GROUPS), tail = n - G;
+  const uint32_t lo = r * Cc, hi = std::min(lo + Cc, G);
+  if (lo < hi) phiUpdater_.UpdatePhi(s.dev_nodes, nbrs, n, lo, hi);
+  for (uint32_t b0 = 0; b0 < tail; b0 += Cc)
+    if ((b0 / Cc) % R == r)
+      clcuda::Check(hipMemcpyAsync(tb + static_cast<size_t>(b0) * K, pv + static_cast<size_t>(G + b0) * K,
+                                   (std::min(b0 + Cc, tail) - b0) * row, hipMemcpyDeviceToDevice, stream),
+                    "hipMemcpyAsync");
+  if (G <= Cc)
+    x.Broadcast(pv, G * row, 0, stream);
+  else
+    x.AllGatherInPlace(pv, Cc * row, stream);
+  if (tail > 0) {
+    for (uint32_t b0 = 0; b0 < tail; b0 += Cc)
+      x.Broadcast(tb + static_cast<size_t>(b0) * K, (std::min(b0 + Cc, tail) - b0) * row, static_cast<int>((b0 / Cc) % R), stream);
+    clcuda::Check(hipMemcpyAsync(pv + static_cast<size_t>(G) * K, tb, tail * row, hipMemcpyDeviceToDevice, stream),
+                  "hipMemcpyAsync");
+  }
+  phiUpdater_.UpdatePi(s.dev_nodes, n);
+
+  betaUpdater_.BeginCall();
+  const uint32_t ne = s.num_edges, per = (ne + R - 1) / R;
+  Float* local = betaUpdater_.GetGrads().data();
+  betaUpdater_.CalculateGrads(&s.dev_edges, ne, std::min(r * per, ne), std::min((r + 1) * per, ne), local);
+  x.AllGather(local, all_grads_->data(), 2 * row, stream);
+  ThrowIfError(ctx_.get(), ammsb_sum_rows_f32(ctx_.get(), all_grads_->data(), R, 2 * K, grads_sum_->data(), stream),
+               "ammsb_sum_rows_f32");
+  betaUpdater_.UpdateTheta(weight, grads_sum_->data());
+  if (!cfg_.async_launch) queue_.Finish();
+}
+
+Float Learner::Perplexity(PerplexityCalculator* calc) {
+  if (!Sharded()) return (*calc)();
+  Exchange& x = *cfg_.exchange;
+  const uint32_t R = static_cast<uint32_t>(x.world()), r = static_cast<uint32_t>(x.rank());
+  calc->BeginCall();
+  const uint32_t H = calc->NumEdges(), per = (H + R - 1) / R;
+  ammsb_ppx_sums* mine = calc->Partial(std::min(r * per, H), std::min((r + 1) * per, H));
+  x.AllGather(mine, all_sums_->data(), sizeof(ammsb_ppx_sums), queue_.stream());
+  std::vector<ammsb_ppx_sums> parts(R);
+  all_sums_->Read(queue_, R, parts.data());
+  ammsb_ppx_sums t = {0.0, 0.0, 0, 0};
+  for (const ammsb_ppx_sums& p : parts) {  // rank order: the same value on every rank
+    t.link_ll += p.link_ll;
+    t.nonlink_ll += p.nonlink_ll;
+    t.link_cnt += p.link_cnt;
+    t.nonlink_cnt += p.nonlink_cnt;
+  }
+  double avg = 0.0;  // perplexity.cc:264-268
+  if (t.link_cnt + t.nonlink_cnt != 0) avg = (t.link_ll + t.nonlink_ll) / static_cast<double>(t.link_cnt + t.nonlink_cnt);
+  return static_cast<Float>(-avg);
+}
+
+// Two pieces of state advance only at their owner: the phi streams of each rank's group block and the running-mean
+// perplexity of each rank's edge slice.  A collective: every rank calls Serialize, after which any rank's stream is
+// the checkpoint (and restarts with any world size).
+void Learner::GatherShardedState() {
+  if (!Sharded()) return;
+  Exchange& x = *cfg_.exchange;
+  const uint32_t R = static_cast<uint32_t>(x.world());
+  DrainAsync();
+  queue_.Finish();
+  const uint64_t L = phiUpdater_.Local(), count = phiUpdater_.Rand().GetSeeds().Count();
+  ammsb_seed* seeds = phiUpdater_.Rand().Get();
+  for (uint32_t b = 0; b < R; ++b) {
+    const uint64_t lo = static_cast<uint64_t>(b) * cc_ * L, hi = std::min<uint64_t>(std::min<uint64_t>((b + 1ull) * cc_, AMMSB_MAX_GROUPS) * L, count);
+    if (lo >= hi) break;
+    x.Broadcast(seeds + lo, (hi - lo) * sizeof(ammsb_seed), static_cast<int>(b), queue_.stream());
+  }
+  std::vector<PerplexityCalculator*> calcs;
+  if (trainingPerplexity_) calcs.push_back(trainingPerplexity_.get());
+  calcs.push_back(&heldoutPerplexity_);
+  for (PerplexityCalculator* c : calcs) {
+    const uint32_t H = c->NumEdges(), per = (H + R - 1) / R;
+    for (uint32_t q = 0; q < R; ++q) {
+      const uint32_t lo = std::min(q * per, H), hi = std::min((q + 1) * per, H);
+      if (lo < hi) x.Broadcast(c->PerEdge().data() + lo, (hi - lo) * sizeof(Float), static_cast<int>(q), queue_.stream());
+    }
+  }
+  queue_.Finish();
+}
+
 Float Learner::TrainingPerplexity() {  // learner.cc:204-212
   if (!trainingPerplexity_) throw std::runtime_error("TrainingPerplexity() needs Config::calc_train_ppx");
   const auto t1 = high_resolution_clock::now();
-  const Float ppx = (*trainingPerplexity_)();
+  const Float ppx = Perplexity(trainingPerplexity_.get());
   time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
   return std::exp(ppx);
 }
 
 Float Learner::HeldoutPerplexity() {
   const auto t1 = high_resolution_clock::now();
-  const Float ppx = heldoutPerplexity_();
+  const Float ppx = Perplexity(&heldoutPerplexity_);
   time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
   return std::exp(ppx);
 }
@@ -344,8 +464,7 @@ void Learner::RunAsync(uint32_t max_iters, sig_atomic_t* signaled) {
     enqueue_sample(1 - phase_);
     Sample& s = *samples_[phase_];
     clcuda::Check(hipStreamWaitEvent(main, static_cast<hipEvent_t>(ev_ready_[phase_]), 0), "hipStreamWaitEvent");
-    phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), s.num_nodes);
-    betaUpdater_(&s.dev_edges, s.num_edges, weight);
+    Step(s, weight);
     clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_consumed_[phase_]), main), "hipEventRecord");
     consumed_valid_[phase_] = true;
     enqueued_[phase_] = false;
@@ -430,8 +549,7 @@ void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
     futures_[1 - phase_] = std::async(std::launch::async, &Learner::DoSample, this, samples_[1 - phase_].get());
     samplingTime_ += duration_cast<nanoseconds>(high_resolution_clock::now() - ts).count();
     Sample& s = *samples_[phase_];
-    phiUpdater_(s.dev_nodes, s.neighbor_sampler.GetData(), s.num_nodes);
-    betaUpdater_(&s.dev_edges, s.num_edges, weight);
+    Step(s, weight);
     edges_done_ += s.num_edges;
     phase_ = 1 - phase_;
   }
@@ -466,6 +584,7 @@ bool Learner::Serialize(std::ostream* out) {
   }
   props.weight = weight;
   queue_.Finish();
+  GatherShardedState();
   return ::mcmc::Serialize(out, &beta_, &queue_) && ::mcmc::Serialize(out, &theta_, &queue_) &&
          ::mcmc::Serialize(out, pi_.get(), &queue_) && ::mcmc::Serialize(out, &phi_, &queue_) &&
          phiUpdater_.Serialize(out) && betaUpdater_.Serialize(out) &&

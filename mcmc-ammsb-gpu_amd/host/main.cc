@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mcmc/data.h"
+#include "mcmc/exchange.h"
 #include "mcmc/learner.h"
 
 namespace clcuda = mcmc::clcuda;
@@ -70,7 +71,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < argc; ++i) s << argv[i] << " ";
     std::cerr << "I " << s.str() << std::endl;
   }
-  std::string filename, loadFile, dumpFile, ckptIn, ckptOut;
+  std::string filename, loadFile, dumpFile, ckptIn, ckptOut, exchangeKind;
+  int deviceId = -1;
   mcmc::Config cfg;
   uint32_t max_iters = 100;
   bool dumpDataset = false, loadDataset = false;
@@ -118,6 +120,8 @@ int main(int argc, char** argv) {
       Opt("device-sampling", 0, &cfg.device_sampling, "0 (new: draw mini-batches on the device)"),
       Opt("async", 0, &cfg.async_launch, "0 (new: enqueue-only loop; needs --device-sampling 1)"),
       Opt("graph", 0, &cfg.graph_launch, "0 (new: iterations as captured hipGraphs; needs --async 1)"),
+      OptStr("exchange", 0, &exchangeKind),  // (new) rccl | host: one process per GPU, RANK / WORLD_SIZE / MASTER_* from the env
+      Opt("device", 0, &deviceId, "-1 (new: HIP device; default LOCAL_RANK with --exchange, else 0)"),
       OptStr("checkpoint-in", 0, &ckptIn),    // (new) Learner::Parse before the first iteration
       OptStr("checkpoint-out", 0, &ckptOut),  // (new) Learner::Serialize after the last one
   };
@@ -182,10 +186,25 @@ int main(int argc, char** argv) {
   if (cfg.alpha == 0) cfg.alpha = static_cast<mcmc::Float>(1) / cfg.K;  // main.cc:153
   cfg.E = unique_edges.size();
 
+  if (deviceId < 0) {
+    const char* lr = exchangeKind.empty() ? nullptr : getenv("LOCAL_RANK");
+    deviceId = lr ? atoi(lr) : 0;
+  }
   clcuda::Platform platform((size_t)0);
-  clcuda::Device dev(platform, 0);
+  clcuda::Device dev(platform, static_cast<size_t>(deviceId));
   clcuda::Context context(dev);
   clcuda::Queue queue(context, dev);
+  int rank = 0;
+  if (!exchangeKind.empty()) {
+    try {
+      cfg.exchange = mcmc::Exchange::FromEnvironment(exchangeKind, deviceId);
+    } catch (const std::exception& e) {
+      Fatal(std::string("exchange: ") + e.what());
+    }
+    rank = cfg.exchange->rank();
+    std::cerr << "I exchange " << cfg.exchange->kind() << ": rank " << rank << " of " << cfg.exchange->world()
+              << " on device " << deviceId << std::endl;
+  }
   std::cerr << "I HIP:\n  Platform: " << dev.Vendor() << "\n  Device: " << dev.Name()
             << "\n  Device Driver: " << dev.Version() << std::endl;
   std::cerr << "I Loaded file " << (loadDataset ? loadFile : filename)
@@ -198,17 +217,20 @@ int main(int argc, char** argv) {
     std::ifstream in(ckptIn, std::ios::binary);
     if (!in.good() || !learner.Parse(&in)) Fatal("cannot restore checkpoint " + ckptIn);
   }
-  std::cerr << "I ppx[0] = " << learner.HeldoutPerplexity() << std::endl;
+  // with an exchange every rank computes every value (the calls are collectives); the lines carry the rank
+  const std::string tag = cfg.exchange ? "I [" + std::to_string(rank) + "] " : "I ";
+  std::cerr << tag << "ppx[0] = " << learner.HeldoutPerplexity() << std::endl;
   for (uint64_t i = 0; i < max_iters && !signaled; i += cfg.ppx_interval) {  // main.cc:162-168
     const uint64_t step = std::min<uint64_t>(max_iters - i, cfg.ppx_interval);
     learner.Run(static_cast<uint32_t>(step), &signaled);
-    if (!signaled) std::cerr << "I ppx[" << i + step << "] = " << learner.HeldoutPerplexity() << std::endl;
+    if (!signaled) std::cerr << tag << "ppx[" << i + step << "] = " << learner.HeldoutPerplexity() << std::endl;
     if (!signaled && cfg.calc_train_ppx)
-      std::cerr << "I train ppx[" << i + step << "] = " << learner.TrainingPerplexity() << std::endl;
+      std::cerr << tag << "train ppx[" << i + step << "] = " << learner.TrainingPerplexity() << std::endl;
   }
   if (signaled) std::cerr << "I FORCED TERMINATE" << std::endl;
   if (!ckptOut.empty()) {
-    std::ofstream out(ckptOut, std::ios::binary);
+    // Serialize is a collective with an exchange; the states are identical afterwards and rank 0's file is the checkpoint
+    std::ofstream out(rank == 0 ? ckptOut : std::string("/dev/null"), std::ios::binary);
     if (!learner.Serialize(&out)) Fatal("cannot write checkpoint " + ckptOut);
   }
   learner.PrintStats();

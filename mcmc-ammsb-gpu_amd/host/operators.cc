@@ -1,5 +1,6 @@
 // The reference's operator classes as thin forwards to the C ABI (include/mcmc/operators.h).
 #include "mcmc/operators.h"
+#include "mcmc/exchange.h"
 #include "mcmc/serialize.h"
 
 #include <hip/hip_runtime.h>
@@ -29,6 +30,13 @@ std::shared_ptr<ammsb_ctx> AcquireContext(const Config& cfg, const clcuda::Queue
 namespace {
 uint64_t MaxNodes(const Config& cfg) {  // phi.cc:620-622
   return std::max<uint64_t>(2 * cfg.mini_batch_size, 1 + cfg.trainingGraph->MaxFanOut());
+}
+// rows of phi_vec: with an Exchange the in-place all-gather region is world blocks of ceil(MAX_GROUPS / world) rows
+uint64_t PhiVecRows(const Config& cfg) {
+  uint64_t rows = MaxNodes(cfg);
+  if (cfg.exchange && cfg.exchange->world() > 1)
+    rows = std::max<uint64_t>(rows, AMMSB_MAX_GROUPS + static_cast<uint64_t>(cfg.exchange->world()));
+  return rows;
 }
 uint64_t MaxEdges(const Config& cfg) {  // sample.cc:129
   return std::max<uint64_t>(cfg.mini_batch_size, cfg.trainingGraph->MaxFanOut());
@@ -224,7 +232,7 @@ PhiUpdater::PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Fl
       phi_(phi),
       trainingSet_(trainingSet),
       max_nodes_(MaxNodes(cfg)),
-      phi_vec_(queue.GetContext(), max_nodes_ * cfg.K),
+      phi_vec_(queue.GetContext(), PhiVecRows(cfg) * cfg.K),
       rand_(queue, max_nodes_ * cfg.phi_wg_size, cfg.phi_seed),  // phi.cc:625-629
       count_calls_(0),
       local_(cfg.phi_wg_size),
@@ -266,6 +274,24 @@ void PhiUpdater::operator()(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex
                  "ammsb_update_pi");
     t_update_pi_ += t.StopNs();
   }
+}
+
+void PhiUpdater::UpdatePhi(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex>& neighbors, uint32_t n,
+                           uint32_t group_begin, uint32_t group_end) {
+  if (n == 0) throw std::runtime_error("mini-batch nodes size = 0!");  // phi.cc:732
+  if (n > max_nodes_) throw std::runtime_error("grads too small");     // phi.cc:734-737
+  ThrowIfError(ctx_.get(),
+               ammsb_update_phi(ctx_.get(), beta_.data(), &pi_->Get(), phi_.data(), &trainingSet_->Get(), nodes.data(),
+                                neighbors.data(), n, count_calls_, rand_.Get(), local_, flags_, group_begin, group_end,
+                                phi_vec_.data(), queue_.stream()),
+               "ammsb_update_phi");
+}
+
+void PhiUpdater::UpdatePi(clcuda::Buffer<Vertex>& nodes, uint32_t n) {
+  ThrowIfError(ctx_.get(),
+               ammsb_update_pi(ctx_.get(), &pi_->Get(), phi_.data(), phi_vec_.data(), nodes.data(), n, local_,
+                               queue_.stream()),
+               "ammsb_update_pi");
 }
 
 bool PhiUpdater::Serialize(std::ostream* out) {
@@ -338,6 +364,21 @@ void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Fl
   queue_.Finish();
 }
 
+void BetaUpdater::CalculateGrads(clcuda::Buffer<Edge>* edges, uint32_t num_edges, uint32_t edge_begin, uint32_t edge_end,
+                                 Float* out) {
+  ThrowIfError(ctx_.get(),
+               ammsb_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), &trainingSet_->Get(), edges->data(),
+                                num_edges, edge_begin, edge_end, local_, out, queue_.stream()),
+               "ammsb_beta_grads");
+}
+
+void BetaUpdater::UpdateTheta(Float scale, const Float* grads) {
+  ThrowIfError(ctx_.get(),
+               ammsb_update_theta(ctx_.get(), theta_.data(), beta_.data(), grads, count_calls_, scale, rand_.Get(), 0,
+                                  queue_.stream()),
+               "ammsb_update_theta");
+}
+
 bool BetaUpdater::Serialize(std::ostream* out) {
   // theta_sum_ (beta.cc:20-28) is recomputed by every launch; the record is produced from theta
   std::vector<Float> theta(theta_.Count());
@@ -399,6 +440,15 @@ Float PerplexityCalculator::operator()() {
   double avg = 0.0;  // perplexity.cc:264-268
   if (s.link_cnt + s.nonlink_cnt != 0) avg = (s.link_ll + s.nonlink_ll) / static_cast<double>(s.link_cnt + s.nonlink_cnt);
   return static_cast<Float>(-avg);
+}
+
+ammsb_ppx_sums* PerplexityCalculator::Partial(uint32_t edge_begin, uint32_t edge_end) {
+  const uint32_t H = static_cast<uint32_t>(edges_.Count());
+  ThrowIfError(ctx_.get(),
+               ammsb_perplexity(ctx_.get(), beta_.data(), &pi_->Get(), &edgeSet_->Get(), edges_.data(), H, edge_begin,
+                                edge_end, count_calls_, local_, ppx_per_edge_.data(), sums_.data(), queue_.stream()),
+               "ammsb_perplexity");
+  return sums_.data();
 }
 
 bool PerplexityCalculator::Serialize(std::ostream* out) {

@@ -1,0 +1,211 @@
+"""mcmc::Exchange (include/mcmc/exchange.h), the C++ learner's multi-GPU transport, and the sharded mcmc::Learner
+on top of it.  CPU: the rendezvous and the host-memory collectives with 3 ranks.  GPU: the device collectives
+("host" transport with 3 ranks on the one card; "rccl" with the single rank RCCL accepts there), then
+ammsb_main --exchange host with 2 and 3 ranks against a single rank on the same data: pi, phi_sum, every RNG
+stream and the running perplexity means bit-identical, theta / beta within the gradient sum's re-association."""
+import os
+import re
+import socket
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "mcmc-ammsb-gpu_amd")
+XT, EXE = os.path.join(PKG, "exchange_test"), os.path.join(PKG, "ammsb_main")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    assert os.path.exists(XT) and os.path.exists(EXE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ranks(argv, world, timeout=600, per_rank_args=None):
+    """Start `world` copies of argv, one per rank, all on device 0; returns the CompletedProcess-like results."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        extra = per_rank_args(r) if per_rank_args else []
+        procs.append(subprocess.Popen(argv + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    out = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=timeout)
+            out.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return out
+
+
+def test_rendezvous_and_host_collectives(built):
+    res = _ranks([XT, "host", "hostmem"], 3, timeout=120)
+    for r, (rc, o, e) in enumerate(res):
+        assert rc == 0, e
+        assert o.strip() == "OK %d of 3 host" % r
+
+
+def test_single_rank_needs_no_peer(built):
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([XT, "host", "hostmem"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "OK 0 of 1 host"
+
+
+def test_bad_rank_is_an_error(built):
+    env = dict(os.environ, RANK="3", WORLD_SIZE="2")
+    r = subprocess.run([XT, "host", "hostmem"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "bad RANK / WORLD_SIZE" in r.stderr
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([XT, "carrier-pigeon", "hostmem"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "unknown exchange kind" in r.stderr
+
+
+@pytest.mark.gpu
+def test_device_collectives_host_transport(built):
+    for rc, o, e in _ranks([XT, "host", "device"], 3, timeout=300):
+        assert rc == 0 and o.startswith("OK"), e
+
+
+@pytest.mark.gpu
+def test_device_collectives_rccl_single_rank(built):
+    # RCCL refuses two ranks on one device; the one-rank communicator still goes through init and all three calls
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([XT, "rccl", "device"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK 0 of 1 rccl", r.stderr  # after RCCL's banner
+
+
+# ---------------------------------------------------------------- the sharded learner
+
+
+def _records(path):
+    """The checkpoint as its list of length-prefixed records (serialize.h:13-24)."""
+    recs = []
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    while pos < len(data):
+        (n,) = struct.unpack_from("<Q", data, pos)
+        recs.append(data[pos + 8:pos + 8 + n])
+        pos += 8 + n
+    assert pos == len(data)
+    return recs
+
+
+def _ppx_lines(stderr):
+    return [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"ppx\[(\d+)\] = ([0-9.eE+-]+)", stderr)]
+
+
+def _graph_file(path, N, deg, seed):
+    rng = np.random.default_rng(seed)
+    K = 16
+    comm = rng.integers(0, K, N)
+    src = rng.integers(0, N, N * deg // 2)
+    same = rng.random(src.size) < 0.8
+    order = np.argsort(comm, kind="stable")
+    starts = np.searchsorted(comm[order], np.arange(K + 1))
+    pick = rng.random(src.size)
+    c = comm[src]
+    dst_same = order[(starts[c] + (pick * (starts[c + 1] - starts[c])).astype(np.int64)).clip(0, N - 1)]
+    dst = np.where(same, dst_same, rng.integers(0, N, src.size))
+    keep = src != dst
+    with open(path, "w") as f:
+        f.write("# synthetic\n# Nodes: %d\n#\n#\n" % N)
+        np.savetxt(f, np.stack([src[keep], dst[keep]], 1), fmt="%d", delimiter="\t")
+
+
+def _heldout_edges(d):
+    import math
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import hostlib
+    N, ratio, edges = hostlib.load_dataset(d)
+    return 2 * (edges.size - math.ceil((1 - ratio / 2) * edges.size))  # links + as many fake pairs (data.cc:87-126)
+
+
+def _compare(single_ck, rank_ck, K, H):
+    ref = _records(single_ck)
+    for ck in [rank_ck]:
+        got = _records(ck)
+        assert len(got) == len(ref)
+        # the held-out calculator's running means: the one buffer of H floats
+        i_ppx = [i for i, a in enumerate(ref) if 4 * H < len(a) <= 4 * H + 12]
+        assert len(i_ppx) == 1
+        i_ppx = i_ppx[0]
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert len(a) == len(b), i
+            if i < 2:  # beta, theta: [2K] floats after the record header
+                fa = np.frombuffer(a[-8 * K:], dtype=np.float32)
+                fb = np.frombuffer(b[-8 * K:], dtype=np.float32)
+                np.testing.assert_allclose(fb, fa, rtol=2e-4, atol=1e-7)
+            elif i == i_ppx:  # the running means: call 1 saw beta_0 (exact), call 2 the re-associated beta_1
+                fa = np.frombuffer(a[-4 * H:], dtype=np.float32)
+                fb = np.frombuffer(b[-4 * H:], dtype=np.float32)
+                np.testing.assert_allclose(fb, fa, rtol=2e-4)
+            elif len(a) >= 200:  # every buffer: pi blocks, phi_sum, RNG streams, running means, the pending samples
+                assert a == b, "record %d (%d bytes) differs" % (i, len(a))
+
+def _dataset(tmp_path, N, deg, flags, seed):
+    g, d = str(tmp_path / "g.txt"), str(tmp_path / "g.bin.gz")
+    _graph_file(g, N, deg, seed=seed)  # seeds whose held-out cuckoo set builds (the reference's Set can fail, cuckoo.cc:117-129)
+    r = subprocess.run([EXE, "-f", g, "--dump-data", "1", "--dump-file", d] + flags, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return d
+
+
+def _run_case(tmp_path, d, world, flags, iters, interval, ppx_rtol, tag, timeout=900):
+    common = [EXE, "--load-data", "1", "--load-file", d] + flags + ["-x", str(iters), "-i", str(interval)]
+    ck1 = str(tmp_path / (tag + "single.ckpt"))
+    one = subprocess.run(common + ["--checkpoint-out", ck1], capture_output=True, text=True, timeout=timeout)
+    assert one.returncode == 0, one.stderr
+    res = _ranks(common + ["--exchange", "host"], world, timeout=timeout,
+                 per_rank_args=lambda r: ["--checkpoint-out", str(tmp_path / ("%srank%d.ckpt" % (tag, r)))])
+    ppx1 = _ppx_lines(one.stderr)
+    assert len(ppx1) == iters // interval + 1
+    first = None
+    for rc, o, e in res:
+        assert rc == 0, e
+        ppx = _ppx_lines(e)
+        assert [s for s, _ in ppx] == [s for s, _ in ppx1]
+        np.testing.assert_allclose([p for _, p in ppx], [p for _, p in ppx1], rtol=ppx_rtol)
+        first = first or ppx
+        assert ppx == first  # every rank reports the same values
+    return ck1, str(tmp_path / (tag + "rank0.ckpt"))  # the other ranks write to /dev/null: rank 0's is the checkpoint
+
+
+# One iteration is exact in everything but theta / beta: phi and pi read beta_0, which every run shares, and the
+# gradient's per-rank partials re-associate one float sum.  From the second iteration on beta differs in its last
+# bits and the trajectories drift apart like any two roundings of the same chain; those runs compare perplexities.
+
+@pytest.mark.gpu
+def test_two_ranks_small_minibatches_host_sampler(built, tmp_path):
+    """Every launch fits rank 0's block (the broadcast path); reference loop with the host samplers."""
+    K = 32
+    flags = ["-k", str(K), "-m", "64", "-n", "16", "-r", "0.05", "--phi-wg", "64", "--beta-wg", "64", "--ppx-wg", "64"]
+    d = _dataset(tmp_path, 3000, 12, flags, seed=12)
+    _compare(*_run_case(tmp_path, d, 2, flags, iters=1, interval=1, ppx_rtol=1e-5, tag="a"), K, _heldout_edges(d))
+    _run_case(tmp_path, d, 2, flags, iters=150, interval=50, ppx_rtol=3e-3, tag="b")
+
+
+@pytest.mark.gpu
+def test_three_ranks_full_blocks_and_tail_rows(built, tmp_path):
+    """m = 65536 non-link mini-batches: 65537 nodes > MAX_GROUPS, so the all-gather covers every block and the two
+    tail rows are parked and handed out; device sampling, enqueue-only loop."""
+    K = 32
+    flags = ["-k", str(K), "-m", "65536", "-n", "32", "-r", "0.02", "--phi-wg", "32", "--beta-wg", "32", "--ppx-wg", "32",
+             "--device-sampling", "1", "--async", "1"]
+    d = _dataset(tmp_path, 150000, 10, flags, seed=11)
+    _compare(*_run_case(tmp_path, d, 3, flags + ["-s", "NodeNonLink"], iters=1, interval=1, ppx_rtol=1e-5, tag="a"), K, _heldout_edges(d))
+    _run_case(tmp_path, d, 3, flags + ["-s", "Node"], iters=8, interval=4, ppx_rtol=3e-3, tag="b")
