@@ -281,6 +281,13 @@ int ammsb_loop_destroy(ammsb_loop* loop);
  * step_count = first_step_count + i for eps_t.  Does not synchronise. */
 int ammsb_loop_run(ammsb_loop* loop, const ammsb_mb_choice* pending, const ammsb_mb_choice* next, uint32_t n_steps,
                    uint32_t first_step_count, uint32_t parity, void* stream);
+/* The two chains of an iteration (main: phi, pi, beta; sampler: the mini-batch two steps ahead) are ordered on the
+ * device by polling kernels, not by stream events.  A wait that is not satisfied within 5 s gives up instead of
+ * hanging the device; this call synchronises the loop's streams and returns how many did since the last call -- 0 in
+ * every correct run, and callers treat anything else as an error (the steps since then used unfinished
+ * mini-batches).  Tools that run one kernel at a time (rocprofv3 --pmc) starve a polling kernel's producer: set
+ * AMMSB_LOOP_HANDSHAKE=event in the environment before ammsb_loop_create to order the chains with events as well. */
+int ammsb_loop_check(ammsb_loop* loop, uint32_t* wait_timeouts);
 /* (AMMSB_LOOP_TIMESTAMPS) device time in ns at which update_phi of steps first_step .. first_step + n_steps - 1
  * began, and at which the kernel after it (update_pi) began -- update_phi's duration plus one kernel boundary: a
  * slight over-estimate, never an under-estimate.  The last 8192 steps are kept.  Synchronises. */

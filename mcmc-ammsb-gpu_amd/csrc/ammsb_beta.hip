@@ -517,6 +517,11 @@ __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv) {
   *adv.cur_out = adv.ring[c + 1];
   *adv.nxt_out = adv.ring[c + adv.nxt_offset];
   *adv.cursor = c + 1;
+  if (adv.main_seq) {
+    // releases the sampler chain that overwrites the buffer set this step has read and reads the descriptor above
+    __threadfence();
+    __hip_atomic_store(adv.main_seq, *adv.main_seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* beta, const float* grads,
@@ -781,7 +786,7 @@ extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, con
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
-  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u};
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K,
                                                                      ammsb_eps_t(&p, step_count), scale, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u,
@@ -795,7 +800,7 @@ int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float*
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds && desc, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
-  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u};
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K, 0.0f, 0.0f, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc,
                                                                      adv ? *adv : none);

@@ -7,8 +7,13 @@
 // the beta partial rows, one kernel for their sum and the theta/beta step) and the SAMPLER chain that produces the
 // mini-batch of step i + 2 (mini-batch kernels + neighbour sampler).  Sampling runs TWO steps ahead through three
 // buffer sets (the caller's two Sample buffers and one of the loop's own), so a short step -- a link batch is a few
-// dozen edges -- does not wait for the ~60 us sampling chain of a 65536-edge batch; events order the ring
-// (sampler(i) waits for main(i-1), main(i) for sampler(i-2)).  A run starts with the caller's one pending
+// dozen edges -- does not wait for the ~60 us sampling chain of a 65536-edge batch.  The ring is ordered on the
+// device (sampler(i) waits for main(i-1), main(i) for sampler(i-2)): two counters in device memory -- main chains
+// completed, mini-batches available -- a one-lane wait kernel at the head of each chain and a bump at its end (a
+// cross-stream event wait costs ~14-20 us of device time per step on this runtime even when already satisfied;
+// the wait kernel is one more graph node, ~1.6 us).  AMMSB_LOOP_HANDSHAKE=event orders the chains with stream
+// events instead (no polling kernels in the graphs): for profilers that run one kernel at a time, under which a
+// polling kernel would starve the chain it waits for.  A run starts with the caller's one pending
 // mini-batch and ends with exactly one pending mini-batch in the caller's buffer, as the eager loop does, so the
 // two forms can alternate and a checkpoint needs nothing new.  (A fork/join inside ONE graph costs ~40 us per
 // replay on this runtime, an in-line chain exposes the sampler's latency, one step of look-ahead leaves every
@@ -26,9 +31,12 @@
 #include "ammsb_ctx.h"
 #include "ammsb_step.h"
 
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <new>
+#include <thread>
 
 namespace {
 
@@ -41,6 +49,31 @@ __global__ void loop_prime_kernel(const ammsb_step_desc* ring, uint32_t* cursor,
   *cur = ring[0];  // the step that runs next
   *nxt = ring[2];  // the mini-batch its sampler chain produces (two steps ahead)
   *cursor = 0;
+}
+
+// ---- device-side hand-shake.  hs[0] = main chains completed, hs[1] = mini-batches available (both count over the
+// loop's lifetime; at every ammsb_loop_run boundary hs[1] == hs[0] + 1: the one pending mini-batch), hs[2] = waits
+// that gave up (sticky; ammsb_loop_check).  A wait holds while (int)(*a - *b) < min_diff; `b` is only written by the
+// waiting stream itself.
+constexpr int HS_MAIN = 0, HS_AVAIL = 1, HS_TIMEOUTS = 2;
+
+__global__ void loop_wait_kernel(const uint32_t* a, const uint32_t* b, int min_diff, uint32_t* timeouts,
+                                 unsigned long long max_ticks) {
+  const uint32_t have = *b;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(v - have) >= min_diff) return;
+    if (wall_clock64() - t0 > max_ticks) {  // a bug or a kernel-serialising tool: never hang the device
+      atomicAdd(timeouts, 1u);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+__global__ void loop_bump_kernel(uint32_t* counter) {
+  __hip_atomic_store(counter, *counter + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct Stage {
@@ -74,6 +107,9 @@ struct ammsb_loop {
   ammsb_step_desc* d_cur[2];     // descriptor of the step that runs next, by step parity
   ammsb_step_desc* d_nxt[NBUF];  // descriptor of the mini-batch being sampled into buffer set b (a sampler chain may
                                  // still be reading it two main chains later: one per buffer set, not per parity)
+  uint32_t* d_hs;                // hand-shake counters (HS_*)
+  bool use_events;               // AMMSB_LOOP_HANDSHAKE=event: also order the chains with stream events
+  unsigned long long wait_ticks; // a wait gives up after this many wall-clock ticks
   unsigned long long* d_stamps;  // [STAMP_CAP][2] or null
   Stage stage[2];
   int next_stage;
@@ -83,6 +119,12 @@ struct ammsb_loop {
   float w_link, w_nonlink;
   int wall_khz;
   uint64_t graphs_launched;
+  bool serial_launch;  // AMMSB_LOOP_LAUNCH=serial: both chains' graphs from the calling thread
+  bool eager_launch;   // default: the chains' kernels launched one by one from two threads; AMMSB_LOOP_LAUNCH=graph
+                       // replays the captured graphs from two threads instead
+  bool host_prof;  // AMMSB_LOOP_HOSTPROF=1: time the two graph launches of a step on the host, print at destroy
+  double t_side_us, t_main_us, t_run_us, t_pro_us, t_epi_us;
+  uint64_t runs;
 };
 
 namespace {
@@ -109,6 +151,11 @@ int record_sampler(ammsb_loop* lp, int nl, int b, int sp, const ammsb_step_desc*
   ammsb_ctx* ctx = lp->ctx;
   const SampleBuf& o = lp->buf[b];
   const uint32_t m = c.mini_batch;
+  // mini-batch J = hs[AVAIL] goes into the buffer set step J - 3 read: wait for main chains 0 .. J - 3
+  if (!lp->use_events) {
+    loop_wait_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_MAIN, lp->d_hs + HS_AVAIL, -2, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks);
+    LOOP_HIP(lp, hipGetLastError());
+  }
   if (nl)
     LOOP_RC(ammsb_minibatch_link_d(ctx, c.csr_offsets, c.csr_targets, lp->link_edges_cap, o.edges, o.nodes, desc, st));
   else
@@ -117,6 +164,10 @@ int record_sampler(ammsb_loop* lp, int nl, int b, int sp, const ammsb_step_desc*
                                       c.mb_count, desc, st));
   LOOP_RC(ammsb_sample_neighbors_d(ctx, c.nbr_seeds[sp], o.nodes, nl ? lp->link_nodes_cap : m + 1, c.nbr_wg, o.nbr_table,
                                    o.neighbors, desc, st));
+  if (!lp->use_events) {
+    loop_bump_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_AVAIL);
+    LOOP_HIP(lp, hipGetLastError());
+  }
   return AMMSB_OK;
 }
 
@@ -129,13 +180,19 @@ int record_main(ammsb_loop* lp, int cl, int b, int dp, hipStream_t st) {
   const uint32_t m = c.mini_batch;
   const uint32_t cap_nodes = cl ? lp->link_nodes_cap : m + 1;
   const uint32_t cap_edges = cl ? lp->link_edges_cap : m;
+  // step S = hs[MAIN] consumes mini-batch S: wait until S + 1 are available
+  if (!lp->use_events) {
+    loop_wait_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_AVAIL, lp->d_hs + HS_MAIN, 1, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks);
+    LOOP_HIP(lp, hipGetLastError());
+  }
   // (AMMSB_LOOP_TIMESTAMPS) block 0 of update_phi and block 0 of update_pi note the device time they start at
   LOOP_RC(ammsb_update_phi_d(ctx, c.beta, &lp->pi, c.phi_sum, &lp->training, in.nodes, in.neighbors, cap_nodes,
                              c.phi_seeds, c.phi_wg, c.phi_flags, c.phi_vec, cur, lp->d_stamps, st));
   LOOP_RC(ammsb_update_pi_d(ctx, &lp->pi, c.phi_sum, c.phi_vec, in.nodes, cap_nodes, c.phi_wg, cur, lp->d_stamps, st));
   // the last kernel hands ring[c + 1] (next step) and ring[c + 3] over: the batch the next step's sampler chain
   // produces -- into the buffer set this step has just finished reading
-  const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[1 - dp], lp->d_nxt[b], 3u};
+  const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[1 - dp], lp->d_nxt[b], 3u,
+                                  lp->use_events ? nullptr : lp->d_hs + HS_MAIN};
   LOOP_RC(ammsb_beta_step_d(ctx, c.theta, c.beta, &lp->pi, &lp->training, in.edges, cap_edges, c.beta_wg, c.grads,
                             c.beta_seeds, c.beta_flags, cur, &adv, st));
   return AMMSB_OK;
@@ -168,6 +225,12 @@ int capture(ammsb_loop* lp, int kind, int link, int b, int dp, hipGraphExec_t* o
 
 void destroy(ammsb_loop* lp) {
   if (!lp) return;
+  if (lp->host_prof && lp->graphs_launched)
+    fprintf(stderr,
+            "ammsb_loop host profile: %llu steps, hipGraphLaunch sampler %.2f us, main %.2f us per step; %llu runs: %.1f us "
+            "each (prologue %.1f, epilogue %.1f)\n",
+            (unsigned long long)lp->graphs_launched, lp->t_side_us / lp->graphs_launched, lp->t_main_us / lp->graphs_launched,
+            (unsigned long long)lp->runs, lp->t_run_us / lp->runs, lp->t_pro_us / lp->runs, lp->t_epi_us / lp->runs);
   if (lp->main) (void)hipStreamSynchronize(lp->main);
   if (lp->side) (void)hipStreamSynchronize(lp->side);
   for (int a = 0; a < 2; ++a)
@@ -185,6 +248,7 @@ void destroy(ammsb_loop* lp) {
     if (ev) (void)hipEventDestroy(ev);
   if (lp->d_ring) (void)hipFree(lp->d_ring);  // one allocation: ring, cursor, cur/nxt
   if (lp->d_stamps) (void)hipFree(lp->d_stamps);
+  if (lp->d_hs) (void)hipFree(lp->d_hs);
   if (lp->own_mem) (void)hipFree(lp->own_mem);
   if (lp->side) (void)hipStreamDestroy(lp->side);
   if (lp->main) (void)hipStreamDestroy(lp->main);
@@ -301,6 +365,20 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
   lp->d_nxt[1] = lp->d_ring + CHUNK + 7;
   lp->d_nxt[2] = lp->d_ring + CHUNK + 8;
   lp->d_cursor = reinterpret_cast<uint32_t*>(lp->d_ring + n_desc);
+  {
+    CREATE_HIP(hipMalloc(&lp->d_hs, 64));
+    const uint32_t hs0[4] = {0u, 1u, 0u, 0u};  // nothing run yet, the caller's pending mini-batch available
+    CREATE_HIP(hipMemcpy(lp->d_hs, hs0, sizeof hs0, hipMemcpyHostToDevice));
+    const char* mode = getenv("AMMSB_LOOP_HANDSHAKE");
+    lp->use_events = mode && strcmp(mode, "event") == 0;
+    lp->host_prof = getenv("AMMSB_LOOP_HOSTPROF") != nullptr;
+    const char* lm = getenv("AMMSB_LOOP_LAUNCH");
+    lp->serial_launch = lm && strcmp(lm, "serial") == 0;
+    lp->eager_launch = !(lm && strcmp(lm, "graph") == 0) && !lp->serial_launch && !lp->use_events;
+    int khz = 100000;
+    CREATE_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    lp->wait_ticks = 5000ull * (unsigned long long)(khz > 0 ? khz : 100000);  // 5 s
+  }
   for (Stage& st : lp->stage) {
     CREATE_HIP(hipHostMalloc(&st.ring, sizeof(ammsb_step_desc) * (CHUNK + 4), hipHostMallocDefault));
     CREATE_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
@@ -342,6 +420,10 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
   for (uint32_t i = 0; i < n_steps; ++i) LOOP_RC(check_choice(lp, next[i]));
   hipStream_t s = as_stream(stream);
   const uint32_t p0 = parity;
+  const bool ev = lp->use_events;
+  using clk = std::chrono::steady_clock;
+  auto us_since = [](clk::time_point t) { return std::chrono::duration<double, std::micro>(clk::now() - t).count(); };
+  const clk::time_point t_run = clk::now();
   // mini-batch j of this call (j = 0: the pending one; j >= 1: next[j - 1], consumed by step j) lives in buffer set
   // (p0 + j) % 3 and was / is sampled with the neighbour-sampler streams of Sample[(p0 + j) % 2]
   auto choice = [&](uint32_t j) -> const ammsb_mb_choice& { return j == 0 ? *pending : next[j - 1]; };
@@ -350,6 +432,7 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
   uint32_t done = 0;
   while (done < n_steps) {
     const uint32_t cnt = n_steps - done < CHUNK ? n_steps - done : CHUNK;
+    const clk::time_point t_pro = clk::now();
     Stage& st = lp->stage[lp->next_stage];
     lp->next_stage ^= 1;
     if (st.used) LOOP_HIP(lp, hipEventSynchronize(st.done));  // the upload two chunks ago has long executed
@@ -371,29 +454,75 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
       // the sampler chain of step i produces mini-batch i + 2
       LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
       LOOP_RC(record_sampler(lp, choice(1).link ? 1 : 0, (int)((p0 + 1) % NBUF), (int)((p0 + 1) & 1u), lp->d_ring + 1, lp->side));
-      LOOP_HIP(lp, hipEventRecord(lp->ev_first, lp->side));
+      if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_first, lp->side));
     }
+    lp->t_pro_us += us_since(t_pro);
+    if (!ev && cnt >= 32 && !lp->serial_launch) {
+      // With the device-side hand-shake nothing on the host orders the two chains any more: the sampler graphs of
+      // the chunk are launched from a second thread while this one launches the main graphs (a launch costs
+      // 8-18 us of host time, which is what a C1 step costs on the device).
+      hipError_t side_err = hipSuccess;
+      int side_rc = AMMSB_OK, main_rc = AMMSB_OK;
+      const clk::time_point ts = clk::now();
+      std::thread helper([&]() {
+        side_err = hipSetDevice(ctx->device);
+        if (side_err == hipSuccess) side_err = hipStreamWaitEvent(lp->side, lp->ev_prime, 0);
+        for (uint32_t i = 0; i < cnt && side_err == hipSuccess && side_rc == AMMSB_OK; ++i) {
+          const uint32_t gi = done + i;
+          if (gi + 2 > n_steps) break;
+          const int b = (int)((p0 + gi + 2) % NBUF), dp = (int)((p0 + gi) & 1u), nl = choice(gi + 2).link ? 1 : 0;
+          if (lp->eager_launch) side_rc = record_sampler(lp, nl, b, dp, lp->d_nxt[b], lp->side);
+          else side_err = hipGraphLaunch(lp->exec_samp[nl][b][dp], lp->side);
+        }
+      });
+      hipError_t main_err = hipSuccess;
+      for (uint32_t i = 0; i < cnt && main_err == hipSuccess && main_rc == AMMSB_OK; ++i) {
+        const uint32_t gi = done + i;
+        const int b = (int)((p0 + gi) % NBUF), dp = (int)((p0 + gi) & 1u), cl = choice(gi).link ? 1 : 0;
+        if (lp->eager_launch) main_rc = record_main(lp, cl, b, dp, lp->main);
+        else main_err = hipGraphLaunch(lp->exec_main[cl][b][dp], lp->main);
+      }
+      if (lp->host_prof) lp->t_main_us += us_since(ts);
+      helper.join();
+      if (lp->host_prof) lp->t_side_us += us_since(ts);  // (parallel form: main = this thread's loop, sampler = until joined)
+      LOOP_HIP(lp, side_err);
+      LOOP_HIP(lp, main_err);
+      LOOP_RC(side_rc);
+      LOOP_RC(main_rc);
+    } else
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t gi = done + i;  // step index within this call
       const int dp = (int)((p0 + gi) & 1u);
       if (gi + 2 <= n_steps) {  // the call ends with exactly ONE pending mini-batch (n_steps), like the eager loop
         // reads the descriptor the previous step's last kernel (or the prime kernel) handed over, overwrites the
         // buffer set step gi - 1 read
-        LOOP_HIP(lp, hipStreamWaitEvent(lp->side, i == 0 ? lp->ev_prime : lp->ev_main[(gi - 1) % NBUF], 0));
+        // (the chain's own wait kernel holds it until main(gi - 1) is done; the first one of a chunk also needs
+        // the prime kernel, which runs after that on the main stream)
+        if (i == 0) LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
+        else if (ev) LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_main[(gi - 1) % NBUF], 0));
+        const auto t0 = lp->host_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         LOOP_HIP(lp, hipGraphLaunch(lp->exec_samp[choice(gi + 2).link ? 1 : 0][(p0 + gi + 2) % NBUF][dp], lp->side));
-        LOOP_HIP(lp, hipEventRecord(lp->ev_samp[gi % NBUF], lp->side));
+        if (lp->host_prof) lp->t_side_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_samp[gi % NBUF], lp->side));
       }
       // main chain of step gi: its mini-batch was sampled during step gi - 2 (gi = 1: by the ramp-up above)
-      if (gi == 1) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_first, 0));
-      if (gi >= 2) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(gi - 2) % NBUF], 0));
+      if (ev && gi == 1) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_first, 0));
+      if (ev && gi >= 2) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(gi - 2) % NBUF], 0));
+      const auto t1 = lp->host_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
       LOOP_HIP(lp, hipGraphLaunch(lp->exec_main[choice(gi).link ? 1 : 0][(p0 + gi) % NBUF][dp], lp->main));
-      LOOP_HIP(lp, hipEventRecord(lp->ev_main[gi % NBUF], lp->main));
+      if (lp->host_prof) lp->t_main_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+      if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_main[gi % NBUF], lp->main));
     }
     lp->graphs_launched += cnt;
     done += cnt;
   }
+  const clk::time_point t_epi = clk::now();
   // the pending mini-batch (n_steps): wait for its sampler, then move it into the caller's Sample[(p0 + n) % 2]
-  LOOP_HIP(lp, hipStreamWaitEvent(lp->main, n_steps == 1 ? lp->ev_first : lp->ev_samp[(n_steps - 2) % NBUF], 0));
+  if (ev) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, n_steps == 1 ? lp->ev_first : lp->ev_samp[(n_steps - 2) % NBUF], 0));
+  if (!ev) {
+    loop_wait_kernel<<<1, 1, 0, lp->main>>>(lp->d_hs + HS_AVAIL, lp->d_hs + HS_MAIN, 1, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks);
+    LOOP_HIP(lp, hipGetLastError());
+  }
   const uint32_t from = (p0 + n_steps) % NBUF, to = (p0 + n_steps) & 1u;
   if (from != to) {
     const ammsb_mb_choice& ch = choice(n_steps);
@@ -406,6 +535,27 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
   }
   LOOP_HIP(lp, hipEventRecord(lp->ev_out, lp->main));
   LOOP_HIP(lp, hipStreamWaitEvent(s, lp->ev_out, 0));
+  lp->t_epi_us += us_since(t_epi);
+  lp->t_run_us += us_since(t_run);
+  lp->runs += 1;
+  return AMMSB_OK;
+}
+
+// Synchronises the loop's streams and reports how many device-side waits gave up since the last call (0 in any
+// correct run; non-zero means the iterations since then ran on mini-batches that were not ready).
+extern "C" int ammsb_loop_check(ammsb_loop* lp, uint32_t* wait_timeouts) {
+  if (!lp) return AMMSB_EINVAL;
+  ammsb_ctx* ctx = lp->ctx;
+  AMMSB_CHECK_ARG(ctx, wait_timeouts, "null argument");
+  LOOP_HIP(lp, hipStreamSynchronize(lp->side));
+  LOOP_HIP(lp, hipStreamSynchronize(lp->main));
+  uint32_t hs[3] = {0, 0, 0};
+  LOOP_HIP(lp, hipMemcpy(hs, lp->d_hs, sizeof hs, hipMemcpyDeviceToHost));
+  *wait_timeouts = hs[HS_TIMEOUTS];
+  if (hs[HS_TIMEOUTS]) {
+    const uint32_t fix[3] = {hs[HS_MAIN], hs[HS_MAIN] + 1u, 0u};  // back to a consistent boundary state
+    LOOP_HIP(lp, hipMemcpy(lp->d_hs, fix, sizeof fix, hipMemcpyHostToDevice));
+  }
   return AMMSB_OK;
 }
 

@@ -32,6 +32,7 @@ struct ammsb_step_advance {
   ammsb_step_desc* cur_out;     // <- ring[cursor + 1]
   ammsb_step_desc* nxt_out;     // <- ring[cursor + nxt_offset]: the batch the next step's sampler chain produces
   uint32_t nxt_offset;
+  uint32_t* main_seq;  // completed main chains (the loop's device-side handshake, ammsb_loop.hip); bumped last
 };
 
 // ---- descriptor forms (same checks and dispatch as the extern "C" functions; `cap` sizes the grid)

@@ -220,6 +220,13 @@ uint32_t Learner::CandidatesFor(uint64_t u) { return CandidatesForExcluded(exclu
 // valid sample.  The device counts them (sticky); this reads the counter at a synchronisation point.
 void Learner::CheckDeviceSampler() {
   if (!cfg_.device_sampling) return;
+  if (loop_) {
+    uint32_t timeouts = 0;
+    ThrowIfError(ctx_.get(), ammsb_loop_check(loop_, &timeouts), "ammsb_loop_check");
+    if (timeouts)
+      throw std::runtime_error("graph loop: " + std::to_string(timeouts) +
+                               " device-side wait(s) timed out (set AMMSB_LOOP_HANDSHAKE=event under kernel-serialising tools)");
+  }
   uint32_t cnt[2] = {0, 0};
   mb_count_->Read(queue_, 2, cnt);
   if (cnt[1] != 0) {

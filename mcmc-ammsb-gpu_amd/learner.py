@@ -678,6 +678,8 @@ class Learner:
             if f is not None:
                 f.result()
         self.ops.synchronize()
+        if self.loop is not None:
+            self.loop.check()
         if self.dev_sampler is not None:
             self.dev_sampler.check()  # a mini-batch that came up short is an error, never a silent duplicate
 

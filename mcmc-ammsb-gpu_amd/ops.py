@@ -664,6 +664,15 @@ class GraphLoop:
                                                    C.cast(nxt.ctypes.data, C.POINTER(_capi.MbChoice)), n,
                                                    int(first_step), int(parity), _stream()))
 
+    def check(self):
+        """Synchronises the loop's streams; raises if a device-side wait between the two chains gave up (never in a
+        correct run: the steps since the last check would have used unfinished mini-batches)."""
+        n = C.c_uint32(0)
+        self.ctx.check(self.ctx.lib.ammsb_loop_check(self._h, C.byref(n)))
+        if n.value:
+            raise AmmsbError("graph loop: %d device-side wait(s) timed out (a kernel-serialising profiler? set "
+                             "AMMSB_LOOP_HANDSHAKE=event)" % n.value)
+
     def timestamps(self, first_step, n):
         """(begin_ns, end_ns) arrays of update_phi for steps first_step .. first_step + n - 1.  Synchronises."""
         b, e = np.zeros(n, dtype=np.float64), np.zeros(n, dtype=np.float64)
