@@ -334,9 +334,18 @@ def main():
     first_step = phi.count_calls + 1
     edges_before = lrn.edges_done
     sync()
+    prof = None
+    if os.environ.get("AMMSB_BENCH_PROFILE"):  # development aid: cProfile of the enqueue side of the timed region
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     lrn.Run(args.steps)
     t_enq = time.perf_counter() - t0  # host side done enqueueing (the device may still be running)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(14)
     sync()
     dt = time.perf_counter() - t0
     phi.update_phi = orig
@@ -345,7 +354,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     edges_done = lrn.edges_done - edges_before  # identical on every rank: the whole job's mini-batch edges
-    step_log = list(lrn.step_log)
+    step_log = []
+    for rec in lrn.step_log:
+        if isinstance(rec, np.ndarray):  # graph loop: n_edges of a whole call, n_nodes = n_edges + 1
+            step_log.extend(zip(rec.tolist(), (rec + 1).tolist()))
+        else:
+            step_log.append(rec)
     lrn.step_log = None
 
     # per-launch records of update_phi: (seconds, nodes in the mini-batch, nodes this rank's launch processed)

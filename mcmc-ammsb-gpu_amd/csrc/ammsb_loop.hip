@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -461,8 +462,12 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
       // With the device-side hand-shake nothing on the host orders the two chains any more: the sampler graphs of
       // the chunk are launched from a second thread while this one launches the main graphs (a launch costs
       // 8-18 us of host time, which is what a C1 step costs on the device).
+      // The SUBMISSION order stays a valid order of the dependencies (a chain is submitted only after the chain its
+      // wait kernel polls for): streams can share a hardware queue, where a polling kernel submitted ahead of its
+      // producer would hold the queue until it gives up (seen: two learners in one process, every wait timing out).
       hipError_t side_err = hipSuccess;
       int side_rc = AMMSB_OK, main_rc = AMMSB_OK;
+      std::atomic<uint32_t> main_sub(0), side_sub(0);  // chains of this chunk submitted so far
       const clk::time_point ts = clk::now();
       std::thread helper([&]() {
         side_err = hipSetDevice(ctx->device);
@@ -470,18 +475,24 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
         for (uint32_t i = 0; i < cnt && side_err == hipSuccess && side_rc == AMMSB_OK; ++i) {
           const uint32_t gi = done + i;
           if (gi + 2 > n_steps) break;
+          while (main_sub.load(std::memory_order_acquire) < i) std::this_thread::yield();  // sampler(i) polls for main(i - 1)
           const int b = (int)((p0 + gi + 2) % NBUF), dp = (int)((p0 + gi) & 1u), nl = choice(gi + 2).link ? 1 : 0;
           if (lp->eager_launch) side_rc = record_sampler(lp, nl, b, dp, lp->d_nxt[b], lp->side);
           else side_err = hipGraphLaunch(lp->exec_samp[nl][b][dp], lp->side);
+          side_sub.store(i + 1, std::memory_order_release);
         }
+        side_sub.store(cnt + 2, std::memory_order_release);  // nothing more (or an error): never hold the main thread
       });
       hipError_t main_err = hipSuccess;
       for (uint32_t i = 0; i < cnt && main_err == hipSuccess && main_rc == AMMSB_OK; ++i) {
         const uint32_t gi = done + i;
+        while (i >= 2 && side_sub.load(std::memory_order_acquire) < i - 1) std::this_thread::yield();  // main(i) polls for sampler(i - 2)
         const int b = (int)((p0 + gi) % NBUF), dp = (int)((p0 + gi) & 1u), cl = choice(gi).link ? 1 : 0;
         if (lp->eager_launch) main_rc = record_main(lp, cl, b, dp, lp->main);
         else main_err = hipGraphLaunch(lp->exec_main[cl][b][dp], lp->main);
+        main_sub.store(i + 1, std::memory_order_release);
       }
+      main_sub.store(cnt + 2, std::memory_order_release);
       if (lp->host_prof) lp->t_main_us += us_since(ts);
       helper.join();
       if (lp->host_prof) lp->t_side_us += us_since(ts);  // (parallel form: main = this thread's loop, sampler = until joined)

@@ -17,6 +17,7 @@
 #include "ammsb_step.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 using namespace ammsb;
 
@@ -66,11 +67,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // table slot hash (mur
   return x;
 }
 
-__global__ __launch_bounds__(MB_BLOCK) void mb_draw_kernel(ammsb_seed* seeds, MbWork w, uint32_t u, uint32_t N,
-                                                            ammsb_set training, ammsb_set heldout, int has_heldout) {
-  const uint32_t j = blockIdx.x * MB_BLOCK + threadIdx.x;
-  if (w.desc) u = w.desc->u;
-  if (j >= mb_active(w)) return;
+__device__ __forceinline__ void mb_draw_one(ammsb_seed* seeds, const MbWork& w, uint32_t j, uint32_t u, uint32_t N,
+                                            const ammsb_set& training, const ammsb_set& heldout, int has_heldout) {
   ammsb_seed s = seeds[j];
   const uint32_t v = (uint32_t)fast_mod(rng_next(s), fast_mod_init(N));
   seeds[j] = s;
@@ -96,6 +94,14 @@ __global__ __launch_bounds__(MB_BLOCK) void mb_draw_kernel(ammsb_seed* seeds, Mb
   }
 }
 
+__global__ __launch_bounds__(MB_BLOCK) void mb_draw_kernel(ammsb_seed* seeds, MbWork w, uint32_t u, uint32_t N,
+                                                            ammsb_set training, ammsb_set heldout, int has_heldout) {
+  const uint32_t j = blockIdx.x * MB_BLOCK + threadIdx.x;
+  if (w.desc) u = w.desc->u;
+  if (j >= mb_active(w)) return;
+  mb_draw_one(seeds, w, j, u, N, training, heldout, has_heldout);
+}
+
 __device__ __forceinline__ bool mb_keep(const MbWork& w, uint32_t j) {
   if (j >= mb_active(w)) return false;
   const uint32_t c = w.cand[j];
@@ -103,7 +109,7 @@ __device__ __forceinline__ bool mb_keep(const MbWork& w, uint32_t j) {
   const uint32_t v = c & 0x7fffffffu;
   uint32_t h = mix32(v) & (w.H - 1);
   for (uint32_t probes = 0; probes < w.H; ++probes) {
-    const uint64_t t = w.table[h];
+    const uint64_t t = __hip_atomic_load(&w.table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(t >> 32) == v) return (uint32_t)t == j;
     if (t == EMPTY) return false;  // cannot happen: this candidate inserted its v or met it
     h = (h + 1) & (w.H - 1);
@@ -111,15 +117,16 @@ __device__ __forceinline__ bool mb_keep(const MbWork& w, uint32_t j) {
   return false;
 }
 
+template <int NT = MB_BLOCK>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t flag, uint32_t* total) {
-  __shared__ uint32_t wsum[MB_BLOCK / 64];
+  __shared__ uint32_t wsum[NT / 64];
   const unsigned long long ball = __ballot(flag != 0);
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t before = __popcll(ball & ((1ull << lane) - 1));
   if (lane == 0) wsum[wv] = __popcll(ball);
   __syncthreads();
   uint32_t off = 0, tot = 0;
-  for (int i = 0; i < MB_BLOCK / 64; ++i) {
+  for (int i = 0; i < NT / 64; ++i) {
     if (i < (int)wv) off += wsum[i];
     tot += wsum[i];
   }
@@ -177,6 +184,51 @@ __global__ void mb_finish_kernel(uint32_t m, const uint32_t* count, uint64_t* ed
   for (uint32_t r = c + tid; r < m; r += nthreads) {
     edges[r] = edges[r % c];
     nodes[1 + r] = nodes[1 + r % c];
+  }
+}
+
+// The whole non-link chain in ONE block for small mini-batches (capacity <= MB_SMALL_CAP candidates): the four
+// launches above cost ~4 x (3 us + a kernel boundary) when each has a handful of blocks, which is most of the
+// sampling chain of a 1024-edge mini-batch.  Same draws, same table protocol, same candidate-order compaction, same
+// count / shortfall / tail / table-clear effects: the outputs are the four-kernel path's bit for bit.
+constexpr int MB_SMALL_THREADS = 1024;
+constexpr uint32_t MB_SMALL_CAP = 4096;
+
+__global__ __launch_bounds__(MB_SMALL_THREADS) void mb_small_kernel(ammsb_seed* seeds, MbWork w, uint32_t u, uint32_t N,
+                                                                     ammsb_set training, ammsb_set heldout,
+                                                                     int has_heldout, uint32_t m, uint64_t* edges,
+                                                                     uint32_t* nodes, uint32_t* count_out) {
+  if (w.desc) u = w.desc->u;
+  const uint32_t n = mb_active(w), tid = threadIdx.x;
+  for (uint32_t j = tid; j < n; j += MB_SMALL_THREADS) mb_draw_one(seeds, w, j, u, N, training, heldout, has_heldout);
+  __threadfence();
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t j0 = 0; j0 < n; j0 += MB_SMALL_THREADS) {
+    const uint32_t j = j0 + tid;
+    const bool keep = mb_keep(w, j);
+    uint32_t total;
+    const uint32_t rank = base + block_exclusive_scan<MB_SMALL_THREADS>(keep ? 1u : 0u, &total);
+    if (keep && rank < m) {
+      const uint32_t v = w.cand[j] & 0x7fffffffu;
+      edges[rank] = make_edge(u, v);
+      nodes[1 + rank] = v;
+    }
+    base += total;
+    __syncthreads();  // the scan's scratch is reused by the next round
+  }
+  if (tid == 0) {
+    nodes[0] = u;
+    count_out[0] = base;
+    if (base < m) count_out[1] += 1;
+  }
+  for (uint32_t h = tid; h < w.H; h += MB_SMALL_THREADS) w.table[h] = EMPTY;  // every probe of this call is done
+  if (base >= m || base == 0) return;
+  __threadfence();
+  __syncthreads();
+  for (uint32_t r = base + tid; r < m; r += MB_SMALL_THREADS) {  // memory-safe tail, as mb_finish_kernel
+    edges[r] = __hip_atomic_load(&edges[r % base], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nodes[1 + r] = __hip_atomic_load(&nodes[1 + r % base], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -254,6 +306,14 @@ static int minibatch_nonlink_common(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t 
   w.desc = desc;
   const uint32_t nb = n_candidates / MB_BLOCK;
   ammsb_set none = {nullptr, 1, 0};
+  static const bool no_small = getenv("AMMSB_MB_SMALL") && atoi(getenv("AMMSB_MB_SMALL")) == 0;  // A/B and tests
+  if (capacity <= MB_SMALL_CAP && !no_small) {
+    mb_small_kernel<<<1, MB_SMALL_THREADS, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, *training_set,
+                                                  heldout_set ? *heldout_set : none, heldout_set ? 1 : 0, m, edges_out,
+                                                  nodes_out, count_out);
+    AMMSB_LAUNCH_CHECK(ctx);
+    return AMMSB_OK;
+  }
   mb_draw_kernel<<<nb, MB_BLOCK, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, *training_set,
                                          heldout_set ? *heldout_set : none, heldout_set ? 1 : 0);
   mb_count_kernel<<<nb, MB_BLOCK, 0, s>>>(w);

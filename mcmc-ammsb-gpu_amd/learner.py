@@ -172,7 +172,8 @@ class Learner:
         self.time = 0.0
         self.samplingTime = 0.0
         self.edges_done = 0
-        self.step_log = None  # a list here collects (n_edges, n_nodes) of every iteration (bench.py)
+        self.step_log = None  # a list here collects every iteration's sizes (bench.py): (n_edges, n_nodes) per step
+                              # from the eager loop, one int64 array of n_edges per call from the graph loop
         self.samples = [Sample(self, cfg.sample_seeds[0])]
         if cfg.sample_parallel:
             self.samples.append(Sample(self, cfg.sample_seeds[1]))
@@ -431,8 +432,9 @@ class Learner:
             first_ne = smp.sizes(s.choice)[0]
             self.edges_done += int(first_ne + ne.sum())
             if self.step_log is not None:
-                self.step_log.append((first_ne, first_ne + 1))
-                self.step_log.extend(zip(ne.tolist(), (ne + 1).tolist()))
+                # one array of n_edges per call (n_nodes = n_edges + 1 on this path): per-step Python objects here cost
+                # more host time than the launches of a small step
+                self.step_log.append(np.concatenate(([first_ne], ne)).astype(np.int64))
             phi.count_calls += n
             beta.count_calls += n
             self.stepCount += n
