@@ -294,7 +294,7 @@ def main():
                                    graph_launch=use_graph, graph_timestamps=use_graph)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
-    note("learner ready (%s loop)" % ("captured-graph" if lrn.loop is not None else "eager"))
+    note("learner ready (%s loop)" % ("device-descriptor" if lrn.loop is not None else "eager"))
 
     def sync():
         lrn.drain()
@@ -454,7 +454,12 @@ def main():
                        "sampling": "host(rand_r): the reference's stream" if args.host_sampling else
                                    "device: same distribution as sample.cc, NOT its rand_r stream (same seed does not "
                                    "reproduce a reference trajectory; --host-sampling does)",
-                       "loop": "captured hipGraphs (one launch per iteration)" if graphs else "eager (one launch per kernel)",
+                       "loop": ("device-descriptor loop (ammsb_loop): %s" % {
+                           "graph": "captured hipGraphs replayed from two host threads",
+                           "serial": "captured hipGraphs replayed from one host thread"}.get(
+                               os.environ.get("AMMSB_LOOP_LAUNCH", ""), "chains launched directly from two host threads")
+                                + (", stream-event hand-over" if os.environ.get("AMMSB_LOOP_HANDSHAKE") == "event"
+                                   else ", device-side hand-over")) if graphs else "eager (one launch + host bookkeeping per kernel)",
                        "host": "python (ctypes -> C ABI); see cpp_dropin for the C++ mcmc::Learner",
                        "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
                        "phi_split": None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,

@@ -591,11 +591,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
   for (uint64_t i = g; i < st.n_nodes; i += st.G) {
     const uint32_t node = a.nodes[i];
     __syncthreads();  // orders the LDS traffic of consecutive nodes
-    for (uint32_t q = tid; q < n; q += L) {
-      const uint32_t nb = a.neighbors[i * n + q];
-      const bool y = set_has(a.set, make_edge(node, nb));
-      s_nb[q] = nb | (y ? 0x80000000u : 0u);
-    }
+    // the neighbour ids first: the first rows are requested as soon as they are known, and the edge-set probes of
+    // the same neighbours (another dependent round trip) fly together with those rows instead of ahead of them
+    for (uint32_t q = tid; q < n; q += L) s_nb[q] = a.neighbors[i * n + q];
     __syncthreads();
 
     const float phi_sum = a.phi_sum[node];
@@ -609,6 +607,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
 #pragma unroll
     for (uint32_t r = 0; r < (uint32_t)(D - U); ++r)
       if (r < n) request(r, r);  // rows 0 .. D-U-1 fly during the per-node set-up
+    for (uint32_t q = tid; q < n; q += L) {
+      const uint32_t nb = s_nb[q];
+      if (set_has(a.set, make_edge(node, nb))) s_nb[q] = nb | 0x80000000u;  // (loads return in order: after the rows above)
+    }
+    __syncthreads();
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
       grads[p] = f32x2{0.0f, 0.0f};
