@@ -399,7 +399,15 @@ def main():
                 traffic = None
         wgp = cfg.phi_wg_size
         lds_form = K % wgp == 0 and ((wgp == 64 and K // wgp in (4, 8, 16, 32)) or (wgp in (128, 256, 512) and K // wgp == 16))
-        kname = ("update_phi_lds_kernel<%d, %d>" % (K // wgp, wgp // 64)) if lds_form else "update_phi_kernel"  # ammsb_phi.hip dispatch
+        kname = "update_phi_kernel"  # names as in ammsb_phi.hip's dispatch (and in the rocprofv3 kernel trace)
+        if lds_form:
+            kpt = K // wgp
+            if wgp == 64 and kpt == 4 and n % 2 == 0:
+                kname = "update_phi_lds2_kernel<4, 8, %d>" % (4 if n % 4 == 0 else 2)
+            elif wgp == 64 and kpt == 8 and n % 2 == 0:
+                kname = "update_phi_lds2_kernel<8, 4, 2>"
+            else:
+                kname = "update_phi_lds_kernel<%d, %d>" % (kpt, wgp // 64)
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "traffic_source": traffic_source,
