@@ -458,7 +458,8 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
       if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_first, lp->side));
     }
     lp->t_pro_us += us_since(t_pro);
-    if (!ev && cnt >= 32 && !lp->serial_launch) {
+    bool threaded = !ev && cnt >= 32 && !lp->serial_launch;
+    if (threaded) {
       // With the device-side hand-shake nothing on the host orders the two chains any more: the sampler graphs of
       // the chunk are launched from a second thread while this one launches the main graphs (a launch costs
       // 8-18 us of host time, which is what a C1 step costs on the device).
@@ -468,11 +469,12 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
       hipError_t side_err = hipSuccess;
       int side_rc = AMMSB_OK, main_rc = AMMSB_OK;
       std::atomic<uint32_t> main_sub(0), side_sub(0);  // chains of this chunk submitted so far
+      std::atomic<bool> stop(false);                   // the other thread failed: submit nothing more
       const clk::time_point ts = clk::now();
-      std::thread helper([&]() {
+      auto side_body = [&]() {
         side_err = hipSetDevice(ctx->device);
         if (side_err == hipSuccess) side_err = hipStreamWaitEvent(lp->side, lp->ev_prime, 0);
-        for (uint32_t i = 0; i < cnt && side_err == hipSuccess && side_rc == AMMSB_OK; ++i) {
+        for (uint32_t i = 0; i < cnt && side_err == hipSuccess && side_rc == AMMSB_OK && !stop.load(); ++i) {
           const uint32_t gi = done + i;
           if (gi + 2 > n_steps) break;
           while (main_sub.load(std::memory_order_acquire) < i) std::this_thread::yield();  // sampler(i) polls for main(i - 1)
@@ -481,26 +483,37 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
           else side_err = hipGraphLaunch(lp->exec_samp[nl][b][dp], lp->side);
           side_sub.store(i + 1, std::memory_order_release);
         }
+        if (side_err != hipSuccess || side_rc != AMMSB_OK) stop.store(true);
         side_sub.store(cnt + 2, std::memory_order_release);  // nothing more (or an error): never hold the main thread
-      });
-      hipError_t main_err = hipSuccess;
-      for (uint32_t i = 0; i < cnt && main_err == hipSuccess && main_rc == AMMSB_OK; ++i) {
-        const uint32_t gi = done + i;
-        while (i >= 2 && side_sub.load(std::memory_order_acquire) < i - 1) std::this_thread::yield();  // main(i) polls for sampler(i - 2)
-        const int b = (int)((p0 + gi) % NBUF), dp = (int)((p0 + gi) & 1u), cl = choice(gi).link ? 1 : 0;
-        if (lp->eager_launch) main_rc = record_main(lp, cl, b, dp, lp->main);
-        else main_err = hipGraphLaunch(lp->exec_main[cl][b][dp], lp->main);
-        main_sub.store(i + 1, std::memory_order_release);
+      };
+      std::thread helper;
+      try {
+        helper = std::thread(side_body);
+      } catch (...) {  // no thread to be had: this chunk goes through the one-thread form below
+        threaded = false;
       }
-      main_sub.store(cnt + 2, std::memory_order_release);
-      if (lp->host_prof) lp->t_main_us += us_since(ts);
-      helper.join();
-      if (lp->host_prof) lp->t_side_us += us_since(ts);  // (parallel form: main = this thread's loop, sampler = until joined)
-      LOOP_HIP(lp, side_err);
-      LOOP_HIP(lp, main_err);
-      LOOP_RC(side_rc);
-      LOOP_RC(main_rc);
-    } else
+      if (threaded) {
+        hipError_t main_err = hipSuccess;
+        for (uint32_t i = 0; i < cnt && main_err == hipSuccess && main_rc == AMMSB_OK && !stop.load(); ++i) {
+          const uint32_t gi = done + i;
+          while (i >= 2 && side_sub.load(std::memory_order_acquire) < i - 1) std::this_thread::yield();  // main(i) polls for sampler(i - 2)
+          const int b = (int)((p0 + gi) % NBUF), dp = (int)((p0 + gi) & 1u), cl = choice(gi).link ? 1 : 0;
+          if (lp->eager_launch) main_rc = record_main(lp, cl, b, dp, lp->main);
+          else main_err = hipGraphLaunch(lp->exec_main[cl][b][dp], lp->main);
+          main_sub.store(i + 1, std::memory_order_release);
+        }
+        if (main_err != hipSuccess || main_rc != AMMSB_OK) stop.store(true);
+        main_sub.store(cnt + 2, std::memory_order_release);
+        if (lp->host_prof) lp->t_main_us += us_since(ts);
+        helper.join();
+        if (lp->host_prof) lp->t_side_us += us_since(ts);  // (parallel form: main = this thread's loop, sampler = until joined)
+        LOOP_HIP(lp, side_err);
+        LOOP_HIP(lp, main_err);
+        LOOP_RC(side_rc);
+        LOOP_RC(main_rc);
+      }
+    }
+    if (!threaded)
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t gi = done + i;  // step index within this call
       const int dp = (int)((p0 + gi) & 1u);
