@@ -68,6 +68,35 @@ def test_graph_loop_equals_eager_loop(env, small_ds, K, wg, m, strategy):
     eager.close(), graph.close()
 
 
+def test_loop_launch_forms_agree(env, small_ds, monkeypatch):
+    """The loop's forms (read from the environment when the loop is created): chains launched directly from two host
+    threads with the device-side hand-over (default), captured graphs replayed from two threads / from one, and
+    stream events instead of polling kernels (the form for kernel-serialising profilers) -- one trajectory."""
+    ops, hostlib, learner, torch = env
+
+    def run(env_vars):
+        for k in ("AMMSB_LOOP_LAUNCH", "AMMSB_LOOP_HANDSHAKE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env_vars.items():
+            monkeypatch.setenv(k, v)
+        cfg = learner.Config.from_cli_defaults(K=64, mini_batch_size=512, num_node_sample=32, strategy="Node",
+                                               phi_wg_size=64, beta_wg_size=64, ppx_wg_size=64, device_sampling=True,
+                                               graph_launch=True)
+        lrn = learner.Learner(cfg, small_ds)
+        for n in (150, 3, 64):   # 150 and 64 go through the two-thread path (>= 32 steps), 3 through the short one
+            lrn.Run(n)
+        st = _state(ops, lrn)
+        ppx = lrn.HeldoutPerplexity()
+        lrn.close()
+        return st, ppx
+
+    ref, ref_ppx = run({})
+    for form in ({"AMMSB_LOOP_LAUNCH": "graph"}, {"AMMSB_LOOP_LAUNCH": "serial"}, {"AMMSB_LOOP_HANDSHAKE": "event"}):
+        st, ppx = run(form)
+        _same(ref, st)
+        assert ppx == ref_ppx, form
+
+
 def test_graph_and_eager_steps_interleave(env, small_ds):
     """Run() calls may alternate between the two forms on one learner (the pending mini-batch, the sample
     buffers' parity and every stream state carry over): eager 5 + graph 6 + eager 4 + graph 1 == eager 16."""
