@@ -285,8 +285,9 @@ int ammsb_loop_run(ammsb_loop* loop, const ammsb_mb_choice* pending, const ammsb
  * device by polling kernels, not by stream events.  A wait that is not satisfied within 5 s gives up instead of
  * hanging the device; this call synchronises the loop's streams and returns how many did since the last call -- 0 in
  * every correct run, and callers treat anything else as an error (the steps since then used unfinished
- * mini-batches).  Tools that run one kernel at a time (rocprofv3 --pmc) starve a polling kernel's producer: set
- * AMMSB_LOOP_HANDSHAKE=event in the environment before ammsb_loop_create to order the chains with events as well. */
+ * mini-batches).  Tools that run one kernel at a time starve a polling kernel's producer:
+ * AMMSB_LOOP_HANDSHAKE=event in the environment at ammsb_loop_create orders the chains with stream events instead
+ * (the default when rocprofv3 --pmc's ROCPROF_COUNTER_COLLECTION is set; AMMSB_LOOP_HANDSHAKE=flag overrides). */
 int ammsb_loop_check(ammsb_loop* loop, uint32_t* wait_timeouts);
 /* (AMMSB_LOOP_TIMESTAMPS) device time in ns at which update_phi of steps first_step .. first_step + n_steps - 1
  * began, and at which the kernel after it (update_pi) began -- update_phi's duration plus one kernel boundary: a

@@ -13,7 +13,8 @@
 // cross-stream event wait costs ~14-20 us of device time per step on this runtime even when already satisfied;
 // the wait kernel is one more graph node, ~1.6 us).  AMMSB_LOOP_HANDSHAKE=event orders the chains with stream
 // events instead (no polling kernels in the graphs): for profilers that run one kernel at a time, under which a
-// polling kernel would starve the chain it waits for.  A run starts with the caller's one pending
+// polling kernel would starve the chain it waits for (chosen automatically under rocprofv3 --pmc;
+// AMMSB_LOOP_HANDSHAKE=flag insists on the polls).  A run starts with the caller's one pending
 // mini-batch and ends with exactly one pending mini-batch in the caller's buffer, as the eager loop does, so the
 // two forms can alternate and a checkpoint needs nothing new.  (A fork/join inside ONE graph costs ~40 us per
 // replay on this runtime, an in-line chain exposes the sampler's latency, one step of look-ahead leaves every
@@ -371,7 +372,11 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     const uint32_t hs0[4] = {0u, 1u, 0u, 0u};  // nothing run yet, the caller's pending mini-batch available
     CREATE_HIP(hipMemcpy(lp->d_hs, hs0, sizeof hs0, hipMemcpyHostToDevice));
     const char* mode = getenv("AMMSB_LOOP_HANDSHAKE");
-    lp->use_events = mode && strcmp(mode, "event") == 0;
+    // rocprofv3 --pmc (its launcher exports ROCPROF_COUNTER_COLLECTION) runs one kernel at a time: a polling kernel
+    // would starve the chain it waits for, so the event hand-over is the default there
+    const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+    const bool serialising_tool = pmc && pmc[0] && strcmp(pmc, "0") != 0 && strcmp(pmc, "False") != 0 && strcmp(pmc, "false") != 0;
+    lp->use_events = mode ? strcmp(mode, "event") == 0 : serialising_tool;
     lp->host_prof = getenv("AMMSB_LOOP_HOSTPROF") != nullptr;
     const char* lm = getenv("AMMSB_LOOP_LAUNCH");
     lp->serial_launch = lm && strcmp(lm, "serial") == 0;
