@@ -929,6 +929,9 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
       const char* f = getenv("AMMSB_PHI_RING");
       return f ? atoi(f) : 0;
     }();
+    // (tried: rings deep enough to hold all of a node's rows -- <4, 32, 4>, <8, 16, 2>, <16, 1, 8> -- for launches of
+    // a few hundred nodes, i.e. link mini-batches, where the chip is empty and a node's chain of row round trips is
+    // what the launch costs: link steps did not get shorter, C2 44.5 -> 45.9 us, C3 80.7 -> 82.3 us; not kept)
     if (wg == 64) {
       switch (kpt) {
         case 4:
