@@ -466,7 +466,9 @@ def main():
                            "graph": "captured hipGraphs replayed from two host threads",
                            "serial": "captured hipGraphs replayed from one host thread"}.get(
                                os.environ.get("AMMSB_LOOP_LAUNCH", ""), "chains launched directly from two host threads")
-                                + (", stream-event hand-over" if os.environ.get("AMMSB_LOOP_HANDSHAKE") == "event"
+                                + (", stream-event hand-over" if (os.environ.get("AMMSB_LOOP_HANDSHAKE") == "event" or (
+                                    "AMMSB_LOOP_HANDSHAKE" not in os.environ and
+                                    os.environ.get("ROCPROF_COUNTER_COLLECTION", "0") not in ("", "0", "False", "false")))
                                    else ", device-side hand-over")) if graphs else "eager (one launch + host bookkeeping per kernel)",
                        "host": "python (ctypes -> C ABI); see cpp_dropin for the C++ mcmc::Learner",
                        "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
