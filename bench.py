@@ -68,6 +68,20 @@ def pick_wg(K, override, cap):
     return wg
 
 
+def loop_form(graphs):
+    """Which form of ammsb_loop the library takes from the environment (csrc/ammsb_loop.hip reads the same variables)."""
+    if not graphs:
+        return "eager (one launch + host bookkeeping per kernel)"
+    hs = os.environ.get("AMMSB_LOOP_HANDSHAKE")
+    pmc = os.environ.get("ROCPROF_COUNTER_COLLECTION", "0") not in ("", "0", "False", "false")
+    if hs == "event" or (hs is None and pmc):
+        return "device-descriptor loop (ammsb_loop): captured hipGraphs replayed from one host thread, stream-event hand-over"
+    launch = {"graph": "captured hipGraphs replayed from two host threads",
+              "serial": "captured hipGraphs replayed from one host thread"}.get(
+                  os.environ.get("AMMSB_LOOP_LAUNCH", ""), "chains launched directly from two host threads")
+    return "device-descriptor loop (ammsb_loop): %s, device-side hand-over" % launch
+
+
 def host_cpu_info():
     """What the CPU baseline ran on: model name, logical CPUs visible, CPUs this process may use (affinity and
     cgroup quota -- a GPU box hands a container a share of a large host)."""
@@ -462,14 +476,7 @@ def main():
                        "sampling": "host(rand_r): the reference's stream" if args.host_sampling else
                                    "device: same distribution as sample.cc, NOT its rand_r stream (same seed does not "
                                    "reproduce a reference trajectory; --host-sampling does)",
-                       "loop": ("device-descriptor loop (ammsb_loop): %s" % {
-                           "graph": "captured hipGraphs replayed from two host threads",
-                           "serial": "captured hipGraphs replayed from one host thread"}.get(
-                               os.environ.get("AMMSB_LOOP_LAUNCH", ""), "chains launched directly from two host threads")
-                                + (", stream-event hand-over" if (os.environ.get("AMMSB_LOOP_HANDSHAKE") == "event" or (
-                                    "AMMSB_LOOP_HANDSHAKE" not in os.environ and
-                                    os.environ.get("ROCPROF_COUNTER_COLLECTION", "0") not in ("", "0", "False", "false")))
-                                   else ", device-side hand-over")) if graphs else "eager (one launch + host bookkeeping per kernel)",
+                       "loop": loop_form(graphs),
                        "host": "python (ctypes -> C ABI); see cpp_dropin for the C++ mcmc::Learner",
                        "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
                        "phi_split": None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
