@@ -17,6 +17,9 @@ import torch  # noqa: E402
 from mcmc_ammsb_gpu_amd import hostlib, ops  # noqa: E402
 
 
+BATCH = 1  # --batch: launches between the two events (small kernels: the per-launch time in a back-to-back stream)
+
+
 def timeit(fn, reps=5, warm=2):
     for _ in range(warm):
         fn()
@@ -25,10 +28,11 @@ def timeit(fn, reps=5, warm=2):
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(BATCH):
+            fn()
         b.record()
         torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
+        ts.append(a.elapsed_time(b) / BATCH)
     return float(np.median(ts)), float(np.min(ts))
 
 
@@ -44,8 +48,11 @@ def main():
     ap.add_argument("--ppx-wgs", default="64,128,256")
     ap.add_argument("--noise", type=int, default=1)
     ap.add_argument("--only", default="phi,pi,beta,ppx")
+    ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--beta-random", type=int, default=0, help="1: both end points random (no shared row)")
     args = ap.parse_args()
+    global BATCH
+    BATCH = max(1, args.batch)
     N, K, m, n = args.N, args.K, args.m, args.n
     rng = np.random.default_rng(0)
     p = ops.make_params(N, K, E=16 * N, num_node_sample=n)
