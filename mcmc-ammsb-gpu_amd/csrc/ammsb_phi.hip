@@ -929,9 +929,11 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
       const char* f = getenv("AMMSB_PHI_RING");
       return f ? atoi(f) : 0;
     }();
-    // (tried: rings deep enough to hold all of a node's rows -- <4, 32, 4>, <8, 16, 2>, <16, 1, 8> -- for launches of
-    // a few hundred nodes, i.e. link mini-batches, where the chip is empty and a node's chain of row round trips is
-    // what the launch costs: link steps did not get shorter, C2 44.5 -> 45.9 us, C3 80.7 -> 82.3 us; not kept)
+    // (tried: rings deep enough to hold all of a node's rows -- <4, 32, 4>, <16, 1, 8> -- for launches of a few dozen
+    // nodes, i.e. link mini-batches, where the chip is empty: the kernels got slower, 18.8 -> 22.0 us at K = 256 and
+    // 50.4 -> 54.4 us at K = 1024 (kernel trace).  A lone wave is not waiting for rows: it is the dependent-instruction
+    // latency of one wave working through a node -- the reference's one work-group per node, whose lane partials and
+    // RNG streams fix the column-to-lane map, cannot be spread over more waves bit-identically.  Not kept.)
     if (wg == 64) {
       switch (kpt) {
         case 4:
