@@ -551,6 +551,9 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
 template <int KPT, int D, int U>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void update_phi_lds2_kernel(const PhiArgs a) {
   constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
+  // probs[] of the U rows in flight stay in registers when that is at most 16 of them per lane (K = 256: 4 rows x 4
+  // columns, K = 512: 2 x 8): no write-back into the ring slot and re-read between the two passes
+  constexpr bool REGP = U * HP <= 8;
   static_assert(D > U && (D & (D - 1)) == 0 && (U == 2 || U == 4) && (D - U) * PIECES <= 63, "ring depth / rows per step");
   extern __shared__ __align__(16) char smem[];  // [D][KW] ring, [KW] normals, [n] u32 (id | link bit)
   __shared__ ZigTables zig;
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       float ee[U], sg[U], part[U], lo[U], psum[U];
+      f32x2 prr[REGP ? U : 1][REGP ? HP : 1];
       bool fast[U], all_fast = true;
 #pragma unroll
       for (int r = 0; r < U; ++r) {
@@ -666,8 +670,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
           const f32x2 pin = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
           const f32x2 tt = (pin * bf[p]) * sg[r] + ee[r];
           const f32x2 pr = pi_a[p] * tt;
-          row[r][ln + 128 * p] = pr.x;
-          row[r][ln + 128 * p + 64] = pr.y;
+          if constexpr (REGP) {
+            prr[r][p] = pr;
+          } else {
+            row[r][ln + 128 * p] = pr.x;
+            row[r][ln + 128 * p + 64] = pr.y;
+          }
           part[r] += pr.x;
           part[r] += pr.y;
           lo[r] = fminf(fminf(lo[r], fabsf(pr.x)), fabsf(pr.y));
@@ -696,7 +704,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
           f32x2 v[U];
 #pragma unroll
           for (int r = 0; r < U; ++r) {
-            const f32x2 pr = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
+            f32x2 pr;
+            if constexpr (REGP) pr = prr[r][p];
+            else pr = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
             v[r] = div_exact3(div_exact3(pr, s2[r], r2[r]), den, rden[p]);
           }
 #pragma unroll
@@ -713,7 +723,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
             const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
 #pragma unroll
             for (int p = 0; p < HP; ++p) {
-              const f32x2 pr = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
+              f32x2 pr;
+              if constexpr (REGP) pr = prr[r][p];
+              else pr = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
               f32x2 qv = div_exact3(pr, psum2, rps2);
               qv = div_exact3(qv, pi_a[p] * ps, rden[p]);
               grads[p] += qv - inv_phi_sum;
@@ -722,8 +734,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
 #pragma unroll
             for (int p = 0; p < HP; ++p) {
               const f32x2 den = pi_a[p] * phi_sum;
-              float v0 = row[r][ln + 128 * p] / probs_sum;
-              float v1 = row[r][ln + 128 * p + 64] / probs_sum;
+              float v0, v1;
+              if constexpr (REGP) {
+                v0 = prr[r][p].x / probs_sum;
+                v1 = prr[r][p].y / probs_sum;
+              } else {
+                v0 = row[r][ln + 128 * p] / probs_sum;
+                v1 = row[r][ln + 128 * p + 64] / probs_sum;
+              }
               v0 = v0 / den.x;
               v1 = v1 / den.y;
               grads[p] += f32x2{v0 - inv_phi_sum, v1 - inv_phi_sum};
