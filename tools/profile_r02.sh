@@ -8,6 +8,7 @@ O=gpurun_out/r02
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o c3 -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --cpp-dropin 0 > $O/c3_bench.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -o c2 -- python3 bench.py --workload C2 --steps 200 --warmup 20 --no-cpu-baseline --cpp-dropin 0 > $O/c2_bench.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c1 -o c1 -- python3 bench.py --workload C1 --steps 400 --warmup 40 --no-cpu-baseline --cpp-dropin 0 > $O/c1_bench.log 2>&1 || exit 1
 # the counter passes run one kernel at a time: order the loop's chains with stream events, not polling kernels
 export AMMSB_LOOP_HANDSHAKE=event   # (also the library's own default under --pmc)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench.py --steps 20 --warmup 4 --no-cpu-baseline --cpp-dropin 0 > $O/fetch.log 2>&1 || exit 1
