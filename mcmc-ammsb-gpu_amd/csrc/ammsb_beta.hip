@@ -34,6 +34,7 @@ struct BetaArgs {
   uint32_t edge_begin, edge_end, P, K;
   float epsilon;
   const ammsb_step_desc* desc;  // non-null (captured graph): edges [0, desc->n_edges), P = min(n_edges, P)
+  ammsb_pi_fusion fuse;         // update_pi folded in (LDS kernels at wg 64, with a descriptor): see ammsb_step.h
 };
 
 struct BetaStep {
@@ -213,20 +214,29 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
 typedef __attribute__((address_space(3))) void beta_lds_void_t;
 typedef const __attribute__((address_space(1))) void beta_glb_void_t;
 
-template <int KPT, int W>
+// FUSE (W == 1, descriptor form, node-stratified mini-batch: edge e = (nodes[0], nodes[e + 1]) in either order): the
+// kernel is also update_pi (phi.cc:177-197).  The ring is filled from phi_vec rows instead of pi rows; a row is
+// normalised as it is consumed -- the lane's columns added in ascending order, WG_SUM over the 64 lanes, one IEEE
+// division per column: update_pi_kernel<64, KPT>'s arithmetic -- and written to pi (+ phi_sum), so every pi row of
+// the mini-batch is written exactly once (the shared node's by slot 0) and what the gradient multiplies are the
+// values the separate update_pi would have stored: bit-identical, one launch and one pass over the rows less.
+template <int KPT, int W, bool FUSE = false>
 __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a) {
+  static_assert(!FUSE || W == 1, "the fused form is one wave per slot");
   // L = 64 W lanes per slot: wave wv owns columns 64 wv + ln + L j (the slicing of update_phi_lds_kernel); every
   // wave streams its own slice of the rows, the two WG_SUMs of an edge share one LDS exchange and one barrier.
   constexpr int L = 64 * W;
   constexpr int KW = 64 * KPT;
   constexpr int K = L * KPT, HP = KPT / 2, PIECES = KPT / 4;
   constexpr uint32_t D = 4;  // ring depth: edge t is reduced while the rows of t+1 .. t+3 are in flight
+  constexpr int ST = 2 * HP + 1;  // (fused form) store instructions of one trip: KPT columns of the pi row + phi_sum
   extern __shared__ __align__(16) char smem[];  // per wave [D][KW] floats: row slice of the second end point, then probs
   __shared__ float xsum[W > 1 ? 4 * L : 1];     // two partials per lane, double buffered
   const int tid = threadIdx.x, wv = W == 1 ? 0 : tid >> 6, ln = W == 1 ? tid : tid & 63;
   char* wave_smem = smem + wv * (D * KW * sizeof(float));
   float* ring = reinterpret_cast<float*>(wave_smem);
   const BetaStep st = beta_step(a);
+  if constexpr (FUSE) note_stamp(a.fuse.stamps, a.desc, 1);
   const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks (at least P with a descriptor)
   if (gs >= st.P) return;          // block-uniform
   const float EPS = a.epsilon;
@@ -289,7 +299,9 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     bool y;
     const unsigned long long edge = key_of(t, &y);
     const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)(edge & 0xffffffffu));
-    const float* rb = rpm_row(a.pi, v) + (W == 1 ? 4 * tid : L * (ln >> 4) + 64 * wv + 4 * (ln & 15));
+    const float* rb;
+    if constexpr (FUSE) rb = a.fuse.phi_vec + ((uint64_t)gs + (uint64_t)t * st.P + 1) * K + 4 * tid;  // node e + 1
+    else rb = rpm_row(a.pi, v) + (W == 1 ? 4 * tid : L * (ln >> 4) + 64 * wv + 4 * (ln & 15));
     char* dst = wave_smem + (t % D) * (KW * sizeof(float));
 #pragma unroll
     for (int p = 0; p < PIECES; ++p)
@@ -330,6 +342,29 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   uint32_t cur_u = 0xffffffffu;
 #pragma unroll
   for (int p = 0; p < HP; ++p) pa[p] = f32x2{0.0f, 0.0f};
+  uint32_t shared_node = 0;
+  if constexpr (FUSE) {  // the shared end point: node 0, normalised here by every slot, stored by slot 0
+    shared_node = a.fuse.nodes[0];
+    const float* src = a.fuse.phi_vec;
+    float partial = 0.0f;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      pa[p] = f32x2{src[tid + 2 * L * p], src[tid + 2 * L * p + L]};
+      partial += pa[p].x;
+      partial += pa[p].y;
+    }
+    const float sum = Group<64>::wave_tree64(partial);
+    float* dst = rpm_row(a.pi, shared_node);
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      pa[p] = f32x2{pa[p].x / sum, pa[p].y / sum};
+      if (gs == 0) {
+        dst[tid + 2 * L * p] = pa[p].x;
+        dst[tid + 2 * L * p + L] = pa[p].y;
+      }
+    }
+    if (gs == 0 && tid == 0) a.fuse.phi_sum[shared_node] = sum;
+  }
 
   for (uint32_t t = 0; t < D - 1 && t < trips; ++t) request(t);
   for (uint32_t t = 0; t < trips; ++t) {
@@ -343,18 +378,49 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
         kv_next = load_keys(tb + 64, &ym_next);
       }
       request(t + D - 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PIECES) : "memory");  // row t landed, t+1 .. t+3 in flight
+      // row t landed, t+1 .. t+3 in flight.  vmcnt counts stores too and retires in issue order (gfx9 family): the
+      // fused form's pi stores of the previous trip (ST instructions, issued after request(t + D - 2)) are younger
+      // than row t and must not be waited for
+      if (FUSE && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PIECES + ST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PIECES) : "memory");
     } else {
       const uint32_t ahead = trips - 1 - t;  // 0 .. D-2 rows still in flight behind row t
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (FUSE && t > 0) {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES + ST) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + ST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory");
+      } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     bool y;
     const unsigned long long edge = key_of(t, &y);
     y = __builtin_amdgcn_readfirstlane((int)y) != 0;
     const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(edge >> 32));
-    if (u != cur_u) {
+    f32x2 pbn[FUSE ? HP : 1];
+    if constexpr (FUSE) {
+      // update_pi of the partner (the end point that is not the shared node): normalise its phi_vec row, store it
+      const uint32_t vv = __builtin_amdgcn_readfirstlane((uint32_t)(edge & 0xffffffffu));
+      const uint32_t partner = u == shared_node ? vv : u;
+      float partial = 0.0f;
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        pbn[p] = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
+        partial += pbn[p].x;
+        partial += pbn[p].y;
+      }
+      const float sum = Group<64>::wave_tree64(partial);
+      float* dst = rpm_row(a.pi, partner);
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        pbn[p] = f32x2{pbn[p].x / sum, pbn[p].y / sum};
+        dst[tid + 2 * L * p] = pbn[p].x;
+        dst[tid + 2 * L * p + L] = pbn[p].y;
+      }
+      if (tid == 0) a.fuse.phi_sum[partner] = sum;
+    } else if (u != cur_u) {
       const float* ra = rpm_row(a.pi, u);
 #pragma unroll
       for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[tid + 2 * L * p], ra[tid + 2 * L * p + L]};
@@ -365,7 +431,9 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
-      const f32x2 pb = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
+      f32x2 pb;
+      if constexpr (FUSE) pb = pbn[p];
+      else pb = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
       const f32x2 f = pa[p] * pb;
       scratch += f.x;
       scratch += f.y;
@@ -415,6 +483,13 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 template <int KPT, int W>
 int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   const size_t lds = (size_t)W * 4 * sizeof(float) * 64 * KPT;
+  if constexpr (W == 1) {
+    if (a.fuse.phi_vec) {
+      beta_grads_lds_kernel<KPT, 1, true><<<a.P, 64, lds, s>>>(a);
+      AMMSB_LAUNCH_CHECK(ctx);
+      return AMMSB_OK;
+    }
+  }
   beta_grads_lds_kernel<KPT, W><<<a.P, 64 * W, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
@@ -638,10 +713,27 @@ inline int pick_kpt(uint64_t K, uint32_t L) {
     default: return AMMSB_EINVAL;                                     \
   }
 
+// shapes whose gradient kernel is beta_grads_lds_kernel<KPT, 1>: K = 64 * {4, 8, 16}, rows 16-byte aligned
+static bool beta_fuse_shape(ammsb_ctx* ctx, uint32_t wg) {
+  const uint32_t K = (uint32_t)ctx->params.K;
+  static const bool off = [] {
+    const char* f = getenv("AMMSB_BETA_FORM");
+    const char* g = getenv("AMMSB_LOOP_FUSE_PI");
+    return (f && f[0] == 'r') || (g && atoi(g) == 0);
+  }();
+  return !off && wg == 64 && (K == 256 || K == 512 || K == 1024);
+}
+
+bool ammsb_beta_can_fuse_pi(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg) {
+  // update_pi's WG_SUM is over phi_wg lanes: the fused form reproduces the 64-lane tree only
+  return ctx && phi_wg == 64 && beta_fuse_shape(ctx, beta_wg);
+}
+
 static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
                              const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
                              uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out,
-                             const ammsb_step_desc* desc, bool sum_rows, uint32_t* slots_out, void* stream) {
+                             const ammsb_step_desc* desc, bool sum_rows, uint32_t* slots_out, void* stream,
+                             const ammsb_pi_fusion* fuse = nullptr) {
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && pi && training_set && edges && grads_out, "null argument");
   AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
                   "bad pi descriptor");
@@ -674,6 +766,12 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.K = K;
   a.epsilon = ctx->params.epsilon;
   a.desc = desc;
+  a.fuse = ammsb_pi_fusion{nullptr, nullptr, nullptr, nullptr};
+  if (fuse && fuse->phi_vec) {
+    AMMSB_CHECK_ARG(ctx, desc && fuse->phi_sum && fuse->nodes && beta_fuse_shape(ctx, wg),
+                    "update_pi fusion needs a descriptor and an LDS-kernel shape at wg 64");
+    a.fuse = *fuse;
+  }
   const uint32_t span = edge_end - edge_begin;
   // enough slots to fill an MI355X (256 CUs, ~8 waves each), never more than there are edges.  A function of
   // (span, wg) only -- not of the CU count visible to this process -- so that the summation order of the
@@ -739,14 +837,15 @@ int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, co
 // grads_out and steps theta (falls back to the separate sum and step kernels for shapes the fused one does not take).
 int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
                       const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg, float* grads_out, ammsb_seed* seeds,
-                      uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream) {
+                      uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv,
+                      const ammsb_pi_fusion* fuse, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && desc && adv && seeds && n_edges_cap > 0, "null argument / empty capacity");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
   const bool fused = (2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0;
   uint32_t slots = 0;
   int rc = beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges_cap, 0, n_edges_cap, wg, grads_out, desc,
-                             !fused, &slots, stream);
+                             !fused, &slots, stream, fuse);
   if (rc != AMMSB_OK) return rc;
   if (!fused) return ammsb_update_theta_d(ctx, theta, beta, grads_out, seeds, flags, desc, adv, stream);
   sum_update_theta_kernel<<<2 * K / 8, 256, 0, as_stream(stream)>>>(ctx->grad_partials, slots, 2 * K, grads_out, theta, beta,

@@ -190,13 +190,18 @@ int record_main(ammsb_loop* lp, int cl, int b, int dp, hipStream_t st) {
   // (AMMSB_LOOP_TIMESTAMPS) block 0 of update_phi and block 0 of update_pi note the device time they start at
   LOOP_RC(ammsb_update_phi_d(ctx, c.beta, &lp->pi, c.phi_sum, &lp->training, in.nodes, in.neighbors, cap_nodes,
                              c.phi_seeds, c.phi_wg, c.phi_flags, c.phi_vec, cur, lp->d_stamps, st));
-  LOOP_RC(ammsb_update_pi_d(ctx, &lp->pi, c.phi_sum, c.phi_vec, in.nodes, cap_nodes, c.phi_wg, cur, lp->d_stamps, st));
+  // update_pi: its own launch, or folded into the gradient kernel (every mini-batch of this loop is node-stratified:
+  // edge t joins nodes[0] and nodes[t + 1])
+  const bool fuse_pi = ammsb_beta_can_fuse_pi(ctx, c.phi_wg, c.beta_wg) && lp->pi.num_cols % 4 == 0;
+  const ammsb_pi_fusion fuse = {c.phi_vec, c.phi_sum, in.nodes, lp->d_stamps};
+  if (!fuse_pi)
+    LOOP_RC(ammsb_update_pi_d(ctx, &lp->pi, c.phi_sum, c.phi_vec, in.nodes, cap_nodes, c.phi_wg, cur, lp->d_stamps, st));
   // the last kernel hands ring[c + 1] (next step) and ring[c + 3] over: the batch the next step's sampler chain
   // produces -- into the buffer set this step has just finished reading
   const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[1 - dp], lp->d_nxt[b], 3u,
                                   lp->use_events ? nullptr : lp->d_hs + HS_MAIN};
   LOOP_RC(ammsb_beta_step_d(ctx, c.theta, c.beta, &lp->pi, &lp->training, in.edges, cap_edges, c.beta_wg, c.grads,
-                            c.beta_seeds, c.beta_flags, cur, &adv, st));
+                            c.beta_seeds, c.beta_flags, cur, &adv, fuse_pi ? &fuse : nullptr, st));
   return AMMSB_OK;
 }
 

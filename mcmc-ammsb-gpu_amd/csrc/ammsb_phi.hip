@@ -45,17 +45,8 @@ struct PhiArgs {
   unsigned long long* stamps;   // optional (with desc): block 0 notes the device time at which it starts
 };
 
-// Device wall-clock stamps without extra launches: block 0 of update_phi notes when it starts (slot 0), block 0 of
-// update_pi -- the next kernel on the stream -- when IT starts (slot 1).  The difference is update_phi's duration
-// plus one kernel boundary: a slight over-estimate, never an under-estimate.
-// (not inlined on purpose: inlined at the top of update_phi_lds_kernel<16, 1> it cost the K = 1024 kernel two spilled
-// registers -- 8 bytes of scratch per lane -- for a store one thread of one block makes)
-__device__ __noinline__ void note_stamp_slow(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
-  if (desc && blockIdx.x == 0 && threadIdx.x == 0) stamps[2 * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
-}
-__device__ __forceinline__ void note_stamp(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
-  if (stamps) note_stamp_slow(stamps, desc, which);  // wave-uniform: a call only when time stamps are on
-}
+// (time stamps: note_stamp in ammsb_step.h -- block 0 of update_phi notes when it starts, block 0 of the kernel after
+// it when IT starts)
 
 // the per-iteration scalars, from the descriptor when there is one (block-uniform scalar loads)
 struct PhiStep {

@@ -35,6 +35,32 @@ struct ammsb_step_advance {
   uint32_t* main_seq;  // completed main chains (the loop's device-side handshake, ammsb_loop.hip); bumped last
 };
 
+#ifdef __HIPCC__
+// Device wall-clock stamps without extra launches: block 0 of update_phi notes when it starts (slot 0), block 0 of
+// the next kernel on the stream (update_pi, or the gradient kernel that has update_pi fused in) when IT starts
+// (slot 1).  The difference is update_phi's duration plus one kernel boundary: a slight over-estimate, never an
+// under-estimate.
+// (not inlined on purpose: inlined at the top of update_phi_lds_kernel<16, 1> it cost the K = 1024 kernel two spilled
+// registers -- 8 bytes of scratch per lane -- for a store one thread of one block makes)
+static __device__ __noinline__ void note_stamp_slow(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
+  if (desc && blockIdx.x == 0 && threadIdx.x == 0) stamps[2 * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
+}
+static __device__ __forceinline__ void note_stamp(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
+  if (stamps) note_stamp_slow(stamps, desc, which);  // wave-uniform: a call only when time stamps are on
+}
+#endif
+
+// update_pi folded into the gradient kernel of a captured step (node-stratified mini-batches: edge t = (nodes[0],
+// nodes[t + 1])): the arguments update_pi would have taken; all null = not fused
+struct ammsb_pi_fusion {
+  const float* phi_vec;
+  float* phi_sum;
+  const uint32_t* nodes;
+  unsigned long long* stamps;
+};
+// whether ammsb_beta_step_d can take the fusion for these work-group sizes (else the caller launches update_pi)
+bool ammsb_beta_can_fuse_pi(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg);
+
 // ---- descriptor forms (same checks and dispatch as the extern "C" functions; `cap` sizes the grid)
 int ammsb_update_phi_d(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
                        const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
@@ -50,7 +76,8 @@ int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float*
                          uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream);
 int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
                       const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg, float* grads_out, ammsb_seed* seeds,
-                      uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream);
+                      uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv,
+                      const ammsb_pi_fusion* fuse, void* stream);
 int ammsb_sample_neighbors_d(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes_cap, uint32_t wg,
                              uint32_t* table, uint32_t* packed, const ammsb_step_desc* desc, void* stream);
 int ammsb_minibatch_link_d(ammsb_ctx* ctx, const uint64_t* csr_offsets, const uint32_t* csr_targets, uint32_t n_cap,

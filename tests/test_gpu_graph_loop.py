@@ -47,9 +47,11 @@ def _same(a, b):
 
 
 @pytest.mark.parametrize("K,wg,m,strategy", [(64, 64, 256, "Node"),      # register kernels (one column per lane)
-                                              (256, 64, 512, "Node"),     # LDS-streamed kernels <4, 1>
+                                              (256, 64, 512, "Node"),     # LDS-streamed kernels <4, 1> (+ fused update_pi)
                                               (256, 64, 512, "NodeLink"),  # link batches only: device-read sizes
-                                              (32, 32, 1024, "NodeNonLink")])
+                                              (32, 32, 1024, "NodeNonLink"),
+                                              (512, 64, 300, "Node"),     # <8, 1>: update_pi folded into the gradient
+                                              (1024, 64, 200, "Node")])   # <16, 1>: the C3 kernels
 def test_graph_loop_equals_eager_loop(env, small_ds, K, wg, m, strategy):
     ops, hostlib, learner, torch = env
 
