@@ -117,6 +117,8 @@ class Sample:
         self.ready = L.ops.new_event()      # sampling finished (recorded on self.stream)
         self.consumed = L.ops.new_event()   # the iteration that used this sample finished (main stream)
         self.consumed_valid = False
+        self.copied = L.ops.new_event()     # the host-to-device copies out of pin_edges / pin_nodes have executed
+        self.copied_valid = False
 
 
 class Learner:
@@ -239,10 +241,17 @@ class Learner:
                 if ne > sample.max_edges or nv > sample.max_nodes:
                     raise AmmsbError("%d | %d" % (ne, sample.max_edges))  # learner.cc:184-188
                 sample.edges, sample.nodes_vec = edges, nodes
+                # the staging buffers are read by an asynchronous copy: the one issued for this sample two iterations ago
+                # must have executed before they are overwritten (the enqueue side can run ahead of the device, e.g.
+                # while the first launches load their code: a mini-batch then silently became the next one's)
+                if sample.copied_valid:
+                    ops.sync_event(sample.copied)
                 sample.pin_edges[:ne].copy_(torch.from_numpy(edges.view(np.int64)))
                 sample.pin_nodes[:nv].copy_(torch.from_numpy(nodes.view(np.int32)))
                 sample.dev_edges[:ne].copy_(sample.pin_edges[:ne], non_blocking=True)
                 sample.dev_nodes[:nv].copy_(sample.pin_nodes[:nv], non_blocking=True)
+                ops.record_event(sample.copied)
+                sample.copied_valid = True
             sample.n_edges, sample.n_nodes = int(ne), int(nv)
             sample.neighbor_sampler(sample.n_nodes, sample.dev_nodes)
             ops.record_event(sample.ready)

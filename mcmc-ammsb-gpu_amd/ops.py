@@ -714,6 +714,10 @@ def record_event(ev):
     ev.record()  # on torch's current stream
 
 
+def sync_event(ev):
+    ev.synchronize()  # the HOST waits (wait_event makes the current stream wait)
+
+
 def wait_event(ev):
     ev.wait()  # torch's current stream waits for the event
 

@@ -259,6 +259,10 @@ def wait_event(ev):
     pass
 
 
+def sync_event(ev):
+    pass
+
+
 def synchronize():
     pass
 
