@@ -713,7 +713,7 @@ inline int pick_kpt(uint64_t K, uint32_t L) {
     default: return AMMSB_EINVAL;                                     \
   }
 
-// shapes whose gradient kernel is beta_grads_lds_kernel<KPT, 1>: K = 64 * {4, 8, 16}, rows 16-byte aligned
+// shapes that take the fused form of beta_grads_lds_kernel<KPT, 1>
 static bool beta_fuse_shape(ammsb_ctx* ctx, uint32_t wg) {
   const uint32_t K = (uint32_t)ctx->params.K;
   static const bool off = [] {
@@ -721,7 +721,11 @@ static bool beta_fuse_shape(ammsb_ctx* ctx, uint32_t wg) {
     const char* g = getenv("AMMSB_LOOP_FUSE_PI");
     return (f && f[0] == 'r') || (g && atoi(g) == 0);
   }();
-  return !off && wg == 64 && (K == 256 || K == 512 || K == 1024);
+  // K = 1024 is built and tested too (AMMSB_LOOP_FUSE_PI=2) but not taken by default: at C3 the step time does not
+  // change (the gradient kernel is latency-bound per wave and the normalisation lands on its critical path), while the
+  // shorter main chain moves more of the concurrent sampling chain under update_phi
+  static const bool k1024 = getenv("AMMSB_LOOP_FUSE_PI") && atoi(getenv("AMMSB_LOOP_FUSE_PI")) == 2;
+  return !off && wg == 64 && (K == 256 || K == 512 || (K == 1024 && k1024));
 }
 
 bool ammsb_beta_can_fuse_pi(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg) {

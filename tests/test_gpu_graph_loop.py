@@ -51,7 +51,7 @@ def _same(a, b):
                                               (256, 64, 512, "NodeLink"),  # link batches only: device-read sizes
                                               (32, 32, 1024, "NodeNonLink"),
                                               (512, 64, 300, "Node"),     # <8, 1>: update_pi folded into the gradient
-                                              (1024, 64, 200, "Node")])   # <16, 1>: the C3 kernels
+                                              (1024, 64, 200, "Node")])   # <16, 1>: the C3 kernels (fusion opt-in, below)
 def test_graph_loop_equals_eager_loop(env, small_ds, K, wg, m, strategy):
     ops, hostlib, learner, torch = env
 
@@ -97,6 +97,32 @@ def test_loop_launch_forms_agree(env, small_ds, monkeypatch):
         st, ppx = run(form)
         _same(ref, st)
         assert ppx == ref_ppx, form
+
+
+def test_fused_update_pi_at_k1024(env, small_ds, monkeypatch):
+    """The K = 1024 instantiation of the gradient kernel with update_pi folded in is opt-in (AMMSB_LOOP_FUSE_PI=2; the
+    flag is read once per process, so this runs in a child): the loop still equals the eager loop bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, __graft_entry__ as ge; ge.build()\n"
+        "from mcmc_ammsb_gpu_amd import hostlib, learner, ops\n"
+        "ds = hostlib.Dataset.robust(20000, hostlib.generate_graph(20000, 16, 16, seed=7), heldout_ratio=0.02, rand_seed=3)\n"
+        "def make(g):\n"
+        "    cfg = learner.Config.from_cli_defaults(K=1024, mini_batch_size=200, num_node_sample=16, strategy='Node', phi_wg_size=64,\n"
+        "                                           beta_wg_size=64, ppx_wg_size=64, device_sampling=True, graph_launch=g)\n"
+        "    return learner.Learner(cfg, ds)\n"
+        "a, b = make(False), make(True)\n"
+        "for n in (1, 2, 37):\n"
+        "    a.Run(n); b.Run(n); a.drain(); b.drain()\n"
+        "    assert np.array_equal(a.pi.host(), b.pi.host()) and np.array_equal(ops.to_numpy(a.theta), ops.to_numpy(b.theta))\n"
+        "    assert np.array_equal(ops.to_numpy(a.phi), ops.to_numpy(b.phi))\n"
+        "print('OK')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, AMMSB_LOOP_FUSE_PI="2"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_graph_and_eager_steps_interleave(env, small_ds):
