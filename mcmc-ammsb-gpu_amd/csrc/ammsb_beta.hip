@@ -50,12 +50,15 @@ __device__ __forceinline__ BetaStep beta_step(const BetaArgs& a) {
   return st;
 }
 
-template <int L, int KPT>
+// FUSE: update_pi folded in, as in beta_grads_lds_kernel<KPT, 1, true> below (which has the description): the rows come
+// from phi_vec, are normalised with update_pi_kernel<L, KPT>'s arithmetic as they are consumed, and are stored to pi.
+template <int L, int KPT, bool FUSE = false>
 __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaArgs a) {
   using Grp = Group<L>;
   __shared__ float aux[Grp::AUX];
   const int l = Grp::lane();
   const BetaStep st = beta_step(a);
+  if constexpr (FUSE) note_stamp(a.fuse.stamps, a.desc, 1);
   const uint32_t gs = blockIdx.x * Grp::PER_BLOCK + Grp::slot();  // partial-row slot
   const bool live = gs < st.P;
   const uint32_t K = a.K;
@@ -89,6 +92,29 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   const uint32_t trips = (n_edges + st.P - 1) / st.P;  // uniform
   int phase = 0;
 
+  float pa_s[FUSE ? KPT : 1];
+  uint32_t shared_node = 0;
+  if constexpr (FUSE) {  // the shared end point (node 0): normalised by every slot, stored by slot 0
+    shared_node = a.fuse.nodes[0];
+    float partial = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      const float x = a.fuse.phi_vec[k < K ? k : K - 1];
+      pa_s[j] = k < K ? x : 0.0f;
+      partial += pa_s[j];
+    }
+    const float sum = Grp::sum(partial, aux, phase);
+    float* dst = rpm_row(a.pi, shared_node);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint32_t k = l + j * L;
+      pa_s[j] = pa_s[j] / sum;
+      if (gs == 0 && k < K) dst[k] = pa_s[j];
+    }
+    if (gs == 0 && l == 0) a.fuse.phi_sum[shared_node] = sum;
+  }
+
   // Software pipeline.  A slot walks edges e(t) = edge_begin + gs + t * P.  Two dependent latencies sit
   // in front of every edge (its key, then its two rows); both are taken off the critical path:
   //   keys: lane i of the group loads the key of trip tb + i AND probes the cuckoo set for it, one
@@ -114,6 +140,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   float pa[3][KPT], pb[3][KPT];
   bool link[3] = {false, false, false};
   bool have[3] = {false, false, false};
+  uint32_t partner[3] = {0, 0, 0};
   auto fetch = [&](int b, uint32_t t) {
     const uint64_t e_raw = (uint64_t)st.edge_begin + gs + (uint64_t)t * st.P;
     have[b] = live && t < trips && e_raw < st.edge_end;
@@ -124,19 +151,45 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
     const uint32_t bit = (wave_lane & ~(W - 1)) + src;          // that lane's position in the wave
     link[b] = (((first ? ym : ym_next) >> bit) & 1ull) != 0;
     const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
-    const float* ra = rpm_row(a.pi, u);
-    const float* rb = rpm_row(a.pi, v);
+    if constexpr (FUSE) {
+      partner[b] = u == shared_node ? v : u;
+      const float* rb = a.fuse.phi_vec + ((have[b] ? e_raw : (uint64_t)st.edge_begin) + 1) * K;  // node e + 1
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const uint32_t k = l + j * L;
-      const uint32_t ck = k < K ? k : K - 1;  // unconditional loads: a column beyond K shadows column K-1
-      const float xa = ra[ck], xb = rb[ck];
-      pa[b][j] = k < K ? xa : 0.0f;
-      pb[b][j] = xb;
+      for (int j = 0; j < KPT; ++j) {
+        const uint32_t k = l + j * L;
+        const float xb = rb[k < K ? k : K - 1];
+        pa[b][j] = pa_s[j];
+        pb[b][j] = k < K ? xb : 0.0f;
+      }
+    } else {
+      const float* ra = rpm_row(a.pi, u);
+      const float* rb = rpm_row(a.pi, v);
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const uint32_t k = l + j * L;
+        const uint32_t ck = k < K ? k : K - 1;  // unconditional loads: a column beyond K shadows column K-1
+        const float xa = ra[ck], xb = rb[ck];
+        pa[b][j] = k < K ? xa : 0.0f;
+        pb[b][j] = xb;
+      }
     }
   };
   auto consume = [&](int b) {
     const bool y = link[b];
+    if constexpr (FUSE) {  // update_pi of the partner: normalise its phi_vec row, store it (once: this is its edge)
+      float partial = 0.0f;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) partial += pb[b][j];
+      const float sum = Grp::sum(partial, aux, phase);
+      float* dst = rpm_row(a.pi, partner[b]);
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const uint32_t k = l + j * L;
+        pb[b][j] = pb[b][j] / sum;
+        if (have[b] && k < K) dst[k] = pb[b][j];
+      }
+      if (have[b] && l == 0) a.fuse.phi_sum[partner[b]] = sum;
+    }
     float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
     float probs[KPT];
 #pragma unroll
@@ -677,6 +730,13 @@ template <int L, int KPT>
 int launch_grads(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   using Grp = Group<L>;
   const uint32_t blocks = (a.P + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  if constexpr ((L == 32 || L == 64) && KPT <= 2) {  // the short-row shapes that take the fusion (beta_fuse_shape)
+    if (a.fuse.phi_vec) {
+      beta_grads_kernel<L, KPT, true><<<blocks, Grp::BLOCK, 0, s>>>(a);
+      AMMSB_LAUNCH_CHECK(ctx);
+      return AMMSB_OK;
+    }
+  }
   beta_grads_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
@@ -725,12 +785,15 @@ static bool beta_fuse_shape(ammsb_ctx* ctx, uint32_t wg) {
   // change (the gradient kernel is latency-bound per wave and the normalisation lands on its critical path), while the
   // shorter main chain moves more of the concurrent sampling chain under update_phi
   static const bool k1024 = getenv("AMMSB_LOOP_FUSE_PI") && atoi(getenv("AMMSB_LOOP_FUSE_PI")) == 2;
-  return !off && wg == 64 && (K == 256 || K == 512 || (K == 1024 && k1024));
+  if (off) return false;
+  if (wg == 64 && (K == 256 || K == 512 || (K == 1024 && k1024))) return true;  // beta_grads_lds_kernel<KPT, 1, true>
+  return (wg == 32 || wg == 64) && K <= 2 * wg;                                   // beta_grads_kernel<L, 1 | 2, true>
 }
 
 bool ammsb_beta_can_fuse_pi(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg) {
-  // update_pi's WG_SUM is over phi_wg lanes: the fused form reproduces the 64-lane tree only
-  return ctx && phi_wg == 64 && beta_fuse_shape(ctx, beta_wg);
+  // update_pi's WG_SUM is over phi_wg lanes with update_pi_kernel<phi_wg, KPT>'s column ownership: the fused form
+  // reproduces it when the gradient uses the same work-group size
+  return ctx && phi_wg == beta_wg && beta_fuse_shape(ctx, beta_wg);
 }
 
 static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,

@@ -50,6 +50,8 @@ def _same(a, b):
                                               (256, 64, 512, "Node"),     # LDS-streamed kernels <4, 1> (+ fused update_pi)
                                               (256, 64, 512, "NodeLink"),  # link batches only: device-read sizes
                                               (32, 32, 1024, "NodeNonLink"),
+                                              (96, 64, 256, "Node"),      # K not a multiple of the work-group: column guards
+                                              (128, 64, 256, "NodeLink"),  # two columns per lane, register kernels
                                               (512, 64, 300, "Node"),     # <8, 1>: update_pi folded into the gradient
                                               (1024, 64, 200, "Node")])   # <16, 1>: the C3 kernels (fusion opt-in, below)
 def test_graph_loop_equals_eager_loop(env, small_ds, K, wg, m, strategy):
