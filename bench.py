@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--exchange", default=os.environ.get("AMMSB_EXCHANGE", "auto"), choices=["auto", "collective", "p2p"],
+                    help="multi-GPU phi_vec exchange: RCCL all-gather, direct peer sends (one per link), or time both")
     ap.add_argument("--phi-wg", type=int, default=0)
     ap.add_argument("--beta-wg", type=int, default=0)
     ap.add_argument("--ppx-wg", type=int, default=0)
@@ -305,7 +307,7 @@ def main():
                                    beta_wg_size=pick_wg(K, args.beta_wg, 16),  # K=1024 -> 64: the LDS-streamed kernel
                                    ppx_wg_size=pick_wg(K, args.ppx_wg, 16),   # K=1024 -> 64
                                    device_sampling=not args.host_sampling,
-                                   graph_launch=use_graph, graph_timestamps=use_graph)
+                                   graph_launch=use_graph, graph_timestamps=use_graph, phi_exchange=args.exchange)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
     note("learner ready (%s loop)" % ("device-descriptor" if lrn.loop is not None else "eager"))

@@ -75,6 +75,8 @@ class Config:
         self.sample_parallel = True                  # MCMC_SAMPLE_PARALLEL, CMakeLists.txt:42
         self.phi_chunks = 4                          # (new) multi-GPU: phi launches per iteration (exchange overlap)
         self.phi_replicate = "auto"                  # (new) multi-GPU: fraction of groups every rank computes itself
+        self.phi_exchange = "auto"                   # (new) multi-GPU: "collective" (all-gather) | "p2p" (direct peer
+                                                     # sends, one per link) | "auto" (time both at start-up)
         self.force_exchange = False                  # (new, tests) take the multi-rank code path even with one rank
         # (new) whole iterations as captured hipGraphs (include/ammsb.h ammsb_loop): "auto" = whenever it applies
         # (device sampling, one rank); False keeps the eager launch-by-launch loop (the parity form); results are
@@ -151,6 +153,7 @@ class Learner:
             raise AmmsbError("held-out set is empty: raise heldout_ratio")
         max_nodes = dataset.max_nodes(cfg.mini_batch_size)
         self.nch = max(1, int(cfg.phi_chunks)) if self.sharded else 1
+        self.xchg_mode = str(getattr(cfg, "phi_exchange", "auto"))  # "auto" is settled by _calibrate_split
         self.g_rep = 0
         self._set_split(0 if cfg.phi_replicate == "auto" else int(round(float(cfg.phi_replicate) * MAX_GROUPS)))
         # rows for any split: the exchanged blocks may reach past the last group by less than one block each
@@ -306,10 +309,30 @@ class Learner:
         def t_phi():
             phi.update_phi(nodes, nbrs, n_nodes)
 
-        def t_xchg():
-            ops.wait_work(ops.all_gather_rows_async(dist, region, chunk, self.rank, R, self.group))
+        def t_xchg(mode):
+            ops.wait_work(ops.all_gather_rows_async(dist, region, chunk, self.rank, R, self.group, mode=mode))
         T = min(ops.elapsed_ms(t_phi) for _ in range(3))
-        X = min(ops.elapsed_ms(t_xchg) for _ in range(3)) * (n_nodes / float(chunk * R))
+        scale = n_nodes / float(chunk * R)
+        X = min(ops.elapsed_ms(lambda: t_xchg("collective")) for _ in range(3)) * scale
+        x_p2p = None
+        if self.xchg_mode == "auto" and R > 1 and not ops._via_host(dist, self.group):
+            # the direct form (one send per peer and link): time it, and check it against the collective's result
+            ops.synchronize()
+            want = region.double().sum(dim=1)
+            try:
+                x_p2p = min(ops.elapsed_ms(lambda: t_xchg("p2p")) for _ in range(3)) * scale
+                ops.synchronize()
+                if not torch.equal(region.double().sum(dim=1), want):
+                    x_p2p = None
+            except Exception:  # a backend without batched point-to-point: stay with the collective
+                x_p2p = None
+        use_p2p = x_p2p is not None and x_p2p < 0.97 * X
+        if self.xchg_mode == "auto":
+            flag = torch.tensor([1.0 if use_p2p else 0.0], dtype=torch.float64).to(c.device)
+            ops.wait_work(ops.broadcast_async(dist, flag, 0, self.group))   # every rank takes rank 0's choice
+            self.xchg_mode = "p2p" if float(flag.item()) > 0.5 else "collective"
+        if self.xchg_mode == "p2p" and x_p2p is not None:
+            X = x_p2p
         phi.rand.seeds.copy_(keep)
         phi.count_calls = calls
         # T (rho + (1 - rho) / R) = X (1 - rho)
@@ -323,7 +346,8 @@ class Learner:
         t = torch.tensor([rho], dtype=torch.float64)
         t = t.to(c.device)
         ops.wait_work(ops.broadcast_async(dist, t, 0, self.group))
-        self.calibration = {"phi_ms": T, "xchg_ms": X, "rho": float(t.item())}
+        self.calibration = {"phi_ms": T, "xchg_ms": X, "rho": float(t.item()), "exchange": self.xchg_mode,
+                            "xchg_p2p_ms": x_p2p}
         self._set_split(int(float(t.item()) * MAX_GROUPS))
         ops.synchronize()
 
@@ -374,7 +398,8 @@ class Learner:
                 if G - base <= Cc:  # only rank 0's block is live in this chunk: a broadcast is enough
                     works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
                 else:
-                    works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group))
+                    works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group,
+                                                           mode="p2p" if self.xchg_mode == "p2p" else "collective"))
         if rep_hi > rep_tail and not forked:
             phi.update_phi(nodes, nbrs, n_nodes, rep_tail, rep_hi)  # overlaps the exchanges in flight
         for w in works:

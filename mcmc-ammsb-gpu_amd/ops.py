@@ -748,11 +748,15 @@ def _via_host(dist, group):
     return dist.get_backend(group) == "gloo"
 
 
-def all_gather_rows_async(dist, region, chunk, rank, world, group):
+def all_gather_rows_async(dist, region, chunk, rank, world, group, mode="collective"):
     """In-place all-gather of the `world` equal row chunks of `region` (rank r owns chunk r), issued
     asynchronously: RCCL runs it on its own stream behind the work already queued on the current one,
     so the next phi launch overlaps it.  The in-place form (send buffer = own slot of the receive
-    buffer) moves each chunk once."""
+    buffer) moves each chunk once.
+    mode "collective": one all_gather_into_tensor.  mode "p2p": the direct form -- this rank's chunk sent to each
+    of the world - 1 peers and their chunks received, as ONE batch of point-to-point operations (RCCL runs the
+    2 (world - 1) transfers of a batch concurrently, one per xGMI link on a fully connected node, where a ring
+    all-gather is bound by a single link's rate).  Same result; Learner._calibrate_split times both."""
     if _via_host(dist, group):
         mine = region[rank * chunk:(rank + 1) * chunk].cpu()
         parts = [torch.empty_like(mine) for _ in range(world)]
@@ -761,7 +765,22 @@ def all_gather_rows_async(dist, region, chunk, rank, world, group):
             if r != rank:
                 region[r * chunk:(r + 1) * chunk].copy_(parts[r])
         return None
+    if mode == "p2p" and world > 1:
+        return p2p_all_gather_rows(dist, region, chunk, rank, world, group)
     return dist.all_gather_into_tensor(region, region[rank * chunk:(rank + 1) * chunk], group=group, async_op=True)
+
+
+def p2p_all_gather_rows(dist, region, chunk, rank, world, group):
+    """The direct form of the in-place all-gather: one batch of 2 (world - 1) point-to-point operations.  Returns
+    the batch's work handles (wait_work takes the list)."""
+    mine = region[rank * chunk:(rank + 1) * chunk]
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    batch = []
+    for d in range(1, world):  # rank r sends to r + d and receives from r - d in round d: every link busy in every round
+        to, frm = (rank + d) % world, (rank - d) % world
+        batch.append(dist.P2POp(dist.isend, mine, peer(to), group))
+        batch.append(dist.P2POp(dist.irecv, region[frm * chunk:(frm + 1) * chunk], peer(frm), group))
+    return dist.batch_isend_irecv(batch)
 
 
 def broadcast_async(dist, rows, src, group):
@@ -775,8 +794,10 @@ def broadcast_async(dist, rows, src, group):
 
 
 def wait_work(work):
-    if work is not None:
-        work.wait()  # makes the current stream wait for the collective; does not block the host
+    if work is None:
+        return
+    for w in (work if isinstance(work, (list, tuple)) else [work]):
+        w.wait()  # makes the current stream wait for the collective; does not block the host
 
 
 def all_gather_flat(dist, out, local, rank, world, group):

@@ -276,7 +276,7 @@ class _Done:
         pass
 
 
-def all_gather_rows_async(dist, region, chunk, rank, world, group):
+def all_gather_rows_async(dist, region, chunk, rank, world, group, mode="collective"):
     parts = [torch.zeros_like(region[:chunk]) for _ in range(world)]
     dist.all_gather(parts, region[rank * chunk:(rank + 1) * chunk].clone(), group=group)
     for r in range(world):

@@ -179,3 +179,38 @@ def test_world2_checkpoint_is_complete(tmp_path):
     a = open(os.path.join(out, "ckpt_r0.bin"), "rb").read()
     b = open(os.path.join(out, "ckpt_r1.bin"), "rb").read()
     assert len(a) == len(b) and sum(x != y for x, y in zip(a, b)) <= 16   # only the wall-clock fields may differ
+
+
+def _run_p2p(rank, world, port, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import ops
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ok = True
+    for chunk, cols in ((1, 4), (7, 33), (513, 64)):
+        region = torch.full((world * chunk, cols), -1.0)
+        region[rank * chunk:(rank + 1) * chunk] = torch.arange(chunk * cols, dtype=torch.float32).reshape(chunk, cols) + 1000.0 * rank
+        ops.wait_work(ops.p2p_all_gather_rows(dist, region, chunk, rank, world, None))
+        for r in range(world):
+            want = torch.arange(chunk * cols, dtype=torch.float32).reshape(chunk, cols) + 1000.0 * r
+            ok = ok and bool(torch.equal(region[r * chunk:(r + 1) * chunk], want))
+    np.save(os.path.join(outdir, "p2p_%d.npy" % rank), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_all_gather_pairs_up(tmp_path, world):
+    """ops.p2p_all_gather_rows (the direct form of the phi_vec exchange: one batch of point-to-point sends and
+    receives per rank) over gloo with host tensors: every rank ends with every chunk, for 2 and 3 ranks."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_run_p2p, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert bool(np.load(os.path.join(str(tmp_path), "p2p_%d.npy" % r))[0])
