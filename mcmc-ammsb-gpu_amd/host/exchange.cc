@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -200,6 +201,8 @@ class RcclExchange : public Exchange {
     if (star_.rank == 0) Nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
     star_.BroadcastHost(&id, sizeof id, 0);
     Nccl(ncclCommInitRank(&comm_, star_.world, id, star_.rank), "ncclCommInitRank");
+    const char* form = getenv("AMMSB_EXCHANGE_FORM");
+    direct_ = form && std::string(form) == "p2p";
   }
   ~RcclExchange() override {
     if (comm_) ncclCommDestroy(comm_);
@@ -209,6 +212,21 @@ class RcclExchange : public Exchange {
   const char* kind() const override { return "rccl"; }
 
   void AllGatherInPlace(void* dev_region, size_t chunk_bytes, void* stream) override {
+    if (direct_) {
+      // the direct form: this rank's chunk to every peer and theirs back as one group of point-to-point
+      // operations -- RCCL runs them concurrently, one per xGMI link of a fully connected node (a ring is bound by
+      // one link's rate).  AMMSB_EXCHANGE_FORM=p2p; the Python learner times both forms at start-up.
+      char* region = static_cast<char*>(dev_region);
+      hipStream_t s = static_cast<hipStream_t>(stream);
+      Nccl(ncclGroupStart(), "ncclGroupStart");
+      for (int d = 1; d < star_.world; ++d) {
+        const int to = (star_.rank + d) % star_.world, from = (star_.rank - d + star_.world) % star_.world;
+        Nccl(ncclSend(region + star_.rank * chunk_bytes, chunk_bytes, ncclChar, to, comm_, s), "ncclSend");
+        Nccl(ncclRecv(region + from * chunk_bytes, chunk_bytes, ncclChar, from, comm_, s), "ncclRecv");
+      }
+      Nccl(ncclGroupEnd(), "ncclGroupEnd");
+      return;
+    }
     // in place: the send buffer is this rank's slot of the receive buffer (each chunk moves once)
     Nccl(ncclAllGather(static_cast<char*>(dev_region) + star_.rank * chunk_bytes, dev_region, chunk_bytes, ncclChar, comm_,
                        static_cast<hipStream_t>(stream)),
@@ -234,6 +252,7 @@ class RcclExchange : public Exchange {
   }
   Star star_;
   ncclComm_t comm_ = nullptr;
+  bool direct_ = false;
 };
 
 }  // namespace

@@ -85,6 +85,10 @@ def test_device_collectives_rccl_single_rank(built):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([XT, "rccl", "device"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK 0 of 1 rccl", r.stderr  # after RCCL's banner
+    # the direct form of the in-place all-gather (grouped ncclSend / ncclRecv): with one rank an empty group
+    r = subprocess.run([XT, "rccl", "device"], env=dict(env, AMMSB_EXCHANGE_FORM="p2p"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "OK 0 of 1 rccl", r.stderr
 
 
 # ---------------------------------------------------------------- the sharded learner
