@@ -545,13 +545,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
   // probs[] of the U rows in flight stay in registers when that is at most 16 of them per lane (K = 256: 4 rows x 4
   // columns, K = 512: 2 x 8): no write-back into the ring slot and re-read between the two passes
   constexpr bool REGP = U * HP <= 8;
+  // the lane's KPT noise factors sqrt(eps_t phi_k) * normal stay in registers when the first row group draws all of
+  // them (KPT == U): no [KW] LDS slot -- at K = 256 that is the kilobyte that keeps a CU from holding 16 of these
+  // one-wave blocks (8 KiB ring + 1.5 KiB ziggurat tables + 128 B neighbour ids each)
+  constexpr bool REGN = KPT == U;
   static_assert(D > U && (D & (D - 1)) == 0 && (U == 2 || U == 4) && (D - U) * PIECES <= 63, "ring depth / rows per step");
   extern __shared__ __align__(16) char smem[];  // [D][KW] ring, [KW] normals, [n] u32 (id | link bit)
   __shared__ ZigTables zig;
   const int tid = threadIdx.x, ln = tid;
   float* ring = reinterpret_cast<float*>(smem);
-  float* s_noise = ring + D * KW;
-  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + (D + 1) * KW * sizeof(float));
+  float* s_noise = ring + D * KW;  // (unused with REGN)
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + (D + (REGN ? 0 : 1)) * KW * sizeof(float));
+  float nz[REGN ? KPT : 1];
 
   const PhiStep st = phi_step(a);
   note_stamp(a.stamps, a.desc, 0);
@@ -613,8 +618,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
       node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
       const f32x2 ep = den * st.eps_t;
-      s_noise[ln + 128 * p] = sqrtf(ep.x);
-      s_noise[ln + 128 * p + 64] = sqrtf(ep.y);
+      if constexpr (REGN) {
+        nz[2 * p] = sqrtf(ep.x);
+        nz[2 * p + 1] = sqrtf(ep.y);
+      } else {
+        s_noise[ln + 128 * p] = sqrtf(ep.x);
+        s_noise[ln + 128 * p + 64] = sqrtf(ep.y);
+      }
     }
 
     for (uint32_t q = 0; q < n; q += U) {  // n is a multiple of U (dispatch)
@@ -629,9 +639,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       }
       // U of the lane's KPT normals per iteration, drawn while the rows are on their way (ascending column order)
       if (a.noise_on) {
+        if constexpr (REGN) {
+          if (q == 0) {
 #pragma unroll
-        for (int r = 0; r < U; ++r)
-          if (q + r < (uint32_t)KPT) s_noise[ln + 64 * (q + r)] = s_noise[ln + 64 * (q + r)] * rng_normal(rs, &zig);
+            for (int r = 0; r < U; ++r) nz[r] = nz[r] * rng_normal(rs, &zig);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < U; ++r)
+            if (q + r < (uint32_t)KPT) s_noise[ln + 64 * (q + r)] = s_noise[ln + 64 * (q + r)] * rng_normal(rs, &zig);
+        }
       }
       {  // rows q .. q+U-1 landed; rows q+U .. min(q+D-1, n-1) may still be in flight (a multiple of U of them)
         const uint32_t rem = n - U - q < (uint32_t)(D - U) ? n - U - q : (uint32_t)(D - U);
@@ -743,9 +760,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
     }
 
     // normals the loop did not get to (n < KPT): one rolled loop, a single copy of the ziggurat code
-    if (a.noise_on) {
+    if constexpr (!REGN) {  // (REGN: n >= U == KPT, the first row group drew them all)
+      if (a.noise_on) {
 #pragma unroll 1
-      for (uint32_t j = n; j < (uint32_t)KPT; ++j) s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
+        for (uint32_t j = n; j < (uint32_t)KPT; ++j) s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -754,7 +773,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
     const float half = st.eps_t / 2;
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
-      const f32x2 bb = f32x2{s_noise[ln + 128 * p], s_noise[ln + 128 * p + 64]};
+      f32x2 bb;
+      if constexpr (REGN) bb = f32x2{nz[2 * p], nz[2 * p + 1]};
+      else bb = f32x2{s_noise[ln + 128 * p], s_noise[ln + 128 * p + 64]};
       const f32x2 phi_k = pi_a[p] * phi_sum;
       const f32x2 ng = grads[p] * a.Nn;
       f32x2 in = a.alpha - phi_k;
@@ -772,7 +793,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
 
 template <int KPT, int D, int U>
 int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
-  const size_t lds = (size_t)(D + 1) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
   update_phi_lds2_kernel<KPT, D, U><<<n_groups, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
