@@ -75,7 +75,8 @@ def loop_form(graphs):
     if not graphs:
         return "eager (one launch + host bookkeeping per kernel)"
     hs = os.environ.get("AMMSB_LOOP_HANDSHAKE")
-    pmc = os.environ.get("ROCPROF_COUNTER_COLLECTION", "0") not in ("", "0", "False", "false")
+    pmc = any(os.environ.get(v, "0") not in ("", "0", "False", "false")
+              for v in ("ROCPROF_COUNTER_COLLECTION", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"))
     if hs == "event" or (hs is None and pmc):
         return "device-descriptor loop (ammsb_loop): captured hipGraphs replayed from one host thread, stream-event hand-over"
     launch = {"graph": "captured hipGraphs replayed from two host threads",

@@ -380,7 +380,11 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     // rocprofv3 --pmc (its launcher exports ROCPROF_COUNTER_COLLECTION) runs one kernel at a time: a polling kernel
     // would starve the chain it waits for, so the event hand-over is the default there
     const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
-    const bool serialising_tool = pmc && pmc[0] && strcmp(pmc, "0") != 0 && strcmp(pmc, "False") != 0 && strcmp(pmc, "false") != 0;
+    auto truthy = [](const char* v) { return v && v[0] && strcmp(v, "0") != 0 && strcmp(v, "False") != 0 && strcmp(v, "false") != 0; };
+    // (the runtime's own serialising switches make every launch wait for the kernel: a poll launched ahead of its
+    // producer would then block the launching thread as well)
+    const bool serialising_tool = truthy(pmc) || truthy(getenv("AMD_SERIALIZE_KERNEL")) || truthy(getenv("HIP_LAUNCH_BLOCKING")) ||
+                                  truthy(getenv("CUDA_LAUNCH_BLOCKING"));
     lp->use_events = mode ? strcmp(mode, "event") == 0 : serialising_tool;
     lp->host_prof = getenv("AMMSB_LOOP_HOSTPROF") != nullptr;
     const char* lm = getenv("AMMSB_LOOP_LAUNCH");
