@@ -648,7 +648,18 @@ __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv) {
   if (adv.main_seq) {
     // releases the sampler chain that overwrites the buffer set this step has read and reads the descriptor above
     __threadfence();
-    __hip_atomic_store(adv.main_seq, *adv.main_seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t done = *adv.main_seq + 1u;
+    __hip_atomic_store(adv.main_seq, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (adv.avail) {  // hold this kernel (one lane of one block) until the next step's mini-batch has been sampled
+      const unsigned long long t0 = wall_clock64();
+      while ((int)(__hip_atomic_load(adv.avail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - done) < 1) {
+        if (wall_clock64() - t0 > adv.max_ticks) {
+          atomicAdd(adv.timeouts, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
   }
 }
 
@@ -952,7 +963,7 @@ extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, con
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
-  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K,
                                                                      ammsb_eps_t(&p, step_count), scale, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u,
@@ -966,7 +977,7 @@ int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float*
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds && desc, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
-  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr};
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K, 0.0f, 0.0f, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc,
                                                                      adv ? *adv : none);

@@ -9,7 +9,8 @@
 // buffer sets (the caller's two Sample buffers and one of the loop's own), so a short step -- a link batch is a few
 // dozen edges -- does not wait for the ~60 us sampling chain of a 65536-edge batch.  The ring is ordered on the
 // device (sampler(i) waits for main(i-1), main(i) for sampler(i-2)): two counters in device memory -- main chains
-// completed, mini-batches available -- a one-lane wait kernel at the head of each chain and a bump at its end (a
+// completed, mini-batches available -- a one-lane wait kernel at the head of the sampler chain, a poll in the last
+// kernel of the main chain (for the NEXT step's mini-batch) and a bump at the end of each (a
 // cross-stream event wait costs ~14-20 us of device time per step on this runtime even when already satisfied;
 // the wait kernel is one more graph node, ~1.6 us).  AMMSB_LOOP_HANDSHAKE=event orders the chains with stream
 // events instead (no polling kernels in the graphs): for profilers that run one kernel at a time, under which a
@@ -182,11 +183,10 @@ int record_main(ammsb_loop* lp, int cl, int b, int dp, hipStream_t st) {
   const uint32_t m = c.mini_batch;
   const uint32_t cap_nodes = cl ? lp->link_nodes_cap : m + 1;
   const uint32_t cap_edges = cl ? lp->link_edges_cap : m;
-  // step S = hs[MAIN] consumes mini-batch S: wait until S + 1 are available
-  if (!lp->use_events) {
-    loop_wait_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_AVAIL, lp->d_hs + HS_MAIN, 1, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks);
-    LOOP_HIP(lp, hipGetLastError());
-  }
+  // step S = hs[MAIN] consumes mini-batch S, which must be available: the LAST kernel of step S - 1 (below) does not
+  // finish before it is -- no polling kernel in front of this chain (saves a launch and a kernel boundary per step).
+  // The first step of a run needs no poll: at every run boundary the pending mini-batch is available
+  // (hs[AVAIL] == hs[MAIN] + 1, the invariant the epilogue of ammsb_loop_run re-establishes).
   // (AMMSB_LOOP_TIMESTAMPS) block 0 of update_phi and block 0 of update_pi note the device time they start at
   LOOP_RC(ammsb_update_phi_d(ctx, c.beta, &lp->pi, c.phi_sum, &lp->training, in.nodes, in.neighbors, cap_nodes,
                              c.phi_seeds, c.phi_wg, c.phi_flags, c.phi_vec, cur, lp->d_stamps, st));
@@ -198,8 +198,10 @@ int record_main(ammsb_loop* lp, int cl, int b, int dp, hipStream_t st) {
     LOOP_RC(ammsb_update_pi_d(ctx, &lp->pi, c.phi_sum, c.phi_vec, in.nodes, cap_nodes, c.phi_wg, cur, lp->d_stamps, st));
   // the last kernel hands ring[c + 1] (next step) and ring[c + 3] over: the batch the next step's sampler chain
   // produces -- into the buffer set this step has just finished reading
+  const bool hs = !lp->use_events;
   const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[1 - dp], lp->d_nxt[b], 3u,
-                                  lp->use_events ? nullptr : lp->d_hs + HS_MAIN};
+                                  hs ? lp->d_hs + HS_MAIN : nullptr, hs ? lp->d_hs + HS_AVAIL : nullptr,
+                                  hs ? lp->d_hs + HS_TIMEOUTS : nullptr, lp->wait_ticks};
   LOOP_RC(ammsb_beta_step_d(ctx, c.theta, c.beta, &lp->pi, &lp->training, in.edges, cap_edges, c.beta_wg, c.grads,
                             c.beta_seeds, c.beta_flags, cur, &adv, fuse_pi ? &fuse : nullptr, st));
   return AMMSB_OK;
@@ -510,7 +512,8 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
         hipError_t main_err = hipSuccess;
         for (uint32_t i = 0; i < cnt && main_err == hipSuccess && main_rc == AMMSB_OK && !stop.load(); ++i) {
           const uint32_t gi = done + i;
-          while (i >= 2 && side_sub.load(std::memory_order_acquire) < i - 1) std::this_thread::yield();  // main(i) polls for sampler(i - 2)
+          // main(i)'s last kernel polls for mini-batch i + 1, the product of sampler(i - 1)
+          while (i >= 1 && side_sub.load(std::memory_order_acquire) < i) std::this_thread::yield();
           const int b = (int)((p0 + gi) % NBUF), dp = (int)((p0 + gi) & 1u), cl = choice(gi).link ? 1 : 0;
           if (lp->eager_launch) main_rc = record_main(lp, cl, b, dp, lp->main);
           else main_err = hipGraphLaunch(lp->exec_main[cl][b][dp], lp->main);

@@ -17,7 +17,6 @@
 #include "ammsb_step.h"
 
 #include <math.h>
-#include <stdlib.h>
 
 using namespace ammsb;
 
@@ -187,51 +186,6 @@ __global__ void mb_finish_kernel(uint32_t m, const uint32_t* count, uint64_t* ed
   }
 }
 
-// The whole non-link chain in ONE block for small mini-batches (capacity <= MB_SMALL_CAP candidates): the four
-// launches above cost ~4 x (3 us + a kernel boundary) when each has a handful of blocks, which is most of the
-// sampling chain of a 1024-edge mini-batch.  Same draws, same table protocol, same candidate-order compaction, same
-// count / shortfall / tail / table-clear effects: the outputs are the four-kernel path's bit for bit.
-constexpr int MB_SMALL_THREADS = 1024;
-constexpr uint32_t MB_SMALL_CAP = 4096;
-
-__global__ __launch_bounds__(MB_SMALL_THREADS) void mb_small_kernel(ammsb_seed* seeds, MbWork w, uint32_t u, uint32_t N,
-                                                                     ammsb_set training, ammsb_set heldout,
-                                                                     int has_heldout, uint32_t m, uint64_t* edges,
-                                                                     uint32_t* nodes, uint32_t* count_out) {
-  if (w.desc) u = w.desc->u;
-  const uint32_t n = mb_active(w), tid = threadIdx.x;
-  for (uint32_t j = tid; j < n; j += MB_SMALL_THREADS) mb_draw_one(seeds, w, j, u, N, training, heldout, has_heldout);
-  __threadfence();
-  __syncthreads();
-  uint32_t base = 0;
-  for (uint32_t j0 = 0; j0 < n; j0 += MB_SMALL_THREADS) {
-    const uint32_t j = j0 + tid;
-    const bool keep = mb_keep(w, j);
-    uint32_t total;
-    const uint32_t rank = base + block_exclusive_scan<MB_SMALL_THREADS>(keep ? 1u : 0u, &total);
-    if (keep && rank < m) {
-      const uint32_t v = w.cand[j] & 0x7fffffffu;
-      edges[rank] = make_edge(u, v);
-      nodes[1 + rank] = v;
-    }
-    base += total;
-    __syncthreads();  // the scan's scratch is reused by the next round
-  }
-  if (tid == 0) {
-    nodes[0] = u;
-    count_out[0] = base;
-    if (base < m) count_out[1] += 1;
-  }
-  for (uint32_t h = tid; h < w.H; h += MB_SMALL_THREADS) w.table[h] = EMPTY;  // every probe of this call is done
-  if (base >= m || base == 0) return;
-  __threadfence();
-  __syncthreads();
-  for (uint32_t r = base + tid; r < m; r += MB_SMALL_THREADS) {  // memory-safe tail, as mb_finish_kernel
-    edges[r] = __hip_atomic_load(&edges[r % base], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    nodes[1 + r] = __hip_atomic_load(&nodes[1 + r % base], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 __global__ void mb_link_kernel(const uint64_t* offsets, const uint32_t* targets, uint32_t u, uint32_t n,
                                uint64_t* edges, uint32_t* nodes, const ammsb_step_desc* desc) {
   if (desc) {  // captured graph: the grid covers the largest degree
@@ -306,14 +260,9 @@ static int minibatch_nonlink_common(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t 
   w.desc = desc;
   const uint32_t nb = n_candidates / MB_BLOCK;
   ammsb_set none = {nullptr, 1, 0};
-  static const bool no_small = getenv("AMMSB_MB_SMALL") && atoi(getenv("AMMSB_MB_SMALL")) == 0;  // A/B and tests
-  if (capacity <= MB_SMALL_CAP && !no_small) {
-    mb_small_kernel<<<1, MB_SMALL_THREADS, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, *training_set,
-                                                  heldout_set ? *heldout_set : none, heldout_set ? 1 : 0, m, edges_out,
-                                                  nodes_out, count_out);
-    AMMSB_LAUNCH_CHECK(ctx);
-    return AMMSB_OK;
-  }
+  // (tried: draw / count / write / finish as ONE 1024-thread block for capacities <= 4096 candidates, to save three
+  // launches per small mini-batch -- 33 us on one CU against 16 us + three boundaries for the four kernels: the
+  // sampling chain became what bounds a C1 step, 0.0304 -> 0.0362 ms; removed)
   mb_draw_kernel<<<nb, MB_BLOCK, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, *training_set,
                                          heldout_set ? *heldout_set : none, heldout_set ? 1 : 0);
   mb_count_kernel<<<nb, MB_BLOCK, 0, s>>>(w);

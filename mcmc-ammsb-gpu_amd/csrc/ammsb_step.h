@@ -33,6 +33,12 @@ struct ammsb_step_advance {
   ammsb_step_desc* nxt_out;     // <- ring[cursor + nxt_offset]: the batch the next step's sampler chain produces
   uint32_t nxt_offset;
   uint32_t* main_seq;  // completed main chains (the loop's device-side handshake, ammsb_loop.hip); bumped last
+  // ... and then the same thread polls until the NEXT step's mini-batch is available (avail - main_seq >= 1), so that
+  // the next main chain needs no polling kernel of its own in front; a poll that is not satisfied within max_ticks
+  // wall-clock ticks gives up and counts itself in *timeouts
+  const uint32_t* avail;
+  uint32_t* timeouts;
+  unsigned long long max_ticks;
 };
 
 #ifdef __HIPCC__

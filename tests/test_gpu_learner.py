@@ -79,47 +79,6 @@ def test_device_minibatch_sampler(env, small_ds):
     assert ((hist - exp) ** 2 / exp).sum() < 60.0
 
 
-def test_small_minibatch_kernel_matches_the_four_kernel_path(env, small_ds):
-    """Capacities up to 4096 candidates take the one-block kernel (mb_small_kernel); a sampler whose capacity is forced
-    above that takes draw / count / write / finish.  Same streams, same vertex, same candidate count: edges, nodes,
-    counters and stream states must agree bit for bit, for full mini-batches and for one that comes up short."""
-    import torch
-    ops, hostlib, learner = env
-    ds = small_ds
-    m = 1024
-    p = ops.make_params(ds.N, 32, E=ds.E, num_node_sample=8)
-    ctx = ops.Context(p)
-    ts = ops.DeviceSet(ctx, ds.training.Serialize(), ds.training.BinsPerBucket(), ds.training.PrimeIdx())
-    hs = ops.DeviceSet(ctx, ds.heldout.Serialize(), ds.heldout.BinsPerBucket(), ds.heldout.PrimeIdx())
-    off, tgt = ds.training_csr()
-    a = ops.DeviceMiniBatchSampler(ctx, off, tgt, ts, hs, m, seed=(77, 78), host_seed=5)
-    b = ops.DeviceMiniBatchSampler(ctx, off, tgt, ts, hs, m, seed=(77, 78), host_seed=5)
-    assert a.C <= 4096
-    big = 8192   # same streams (a stream's state depends on the seed and its index only), larger table and capacity
-    b.C = big
-    b.rand = ops.Random(ctx, big, (77, 78), mixed=True)
-    b.workspace = torch.full((int(ctx.lib.ammsb_minibatch_workspace_bytes(big)),), 255, dtype=torch.uint8, device=ctx.device)
-    assert np.array_equal(a.rand.host(), b.rand.host()[:a.C])
-    e = ctx.empty((ds.max_edges(m),), torch.int64)
-    v = ctx.empty((ds.max_nodes(m),), torch.int32)
-    e2, v2 = torch.empty_like(e), torch.empty_like(v)
-    choices = [a.choose("NodeNonLink") for _ in range(6)] + [(0, 5, 0, m), (0, 9, 0, m)]   # m draws never give m distinct valid partners: short
-    shorts = 0
-    for ch in choices:
-        for t in (e, v, e2, v2):
-            t.fill_(-1)
-        a.enqueue(ch, e, v)
-        b.enqueue(ch, e2, v2)
-        torch.cuda.synchronize()
-        assert torch.equal(e[:m], e2[:m]) and torch.equal(v[:m + 1], v2[:m + 1])
-        assert torch.equal(a.count, b.count)
-        shorts += int(a.count[0]) < m
-        assert np.array_equal(a.rand.host(), b.rand.host()[:a.C])
-        assert bool((a.workspace[:8 * 1024] == 255).all())   # the table is left empty
-    assert shorts == 2 and int(a.count[1]) == 2
-    ctx.close()
-
-
 @pytest.mark.parametrize("device_sampling", [False, True])
 def test_learner_runs_and_learns(env, small_ds, device_sampling):
     import torch
