@@ -717,7 +717,9 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
     __syncthreads();
   }
   if (r == 0) *reinterpret_cast<float4*>(grads_out + c) = red[0][h];
-  if (blockIdx.x == 0 && threadIdx.x == 0) step_advance(adv);
+  // the hand-over (three dependent round trips, then the poll for the next mini-batch) runs in the block's SECOND wave,
+  // beside the theta step of the first: neither waits for the other
+  if (blockIdx.x == 0 && threadIdx.x == 64) step_advance(adv);
   if (threadIdx.x < 4) {
     const uint32_t k = blockIdx.x * 4 + threadIdx.x;  // columns 2k, 2k+1 = words (t & 1) * 2, +1 of red[0][t >> 1]
     const float4 g = red[0][threadIdx.x >> 1];
