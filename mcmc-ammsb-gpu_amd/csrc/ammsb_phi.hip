@@ -200,12 +200,101 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
       }
     };
 
+    // Short rows (at most two columns per lane): what a row costs is not its bytes but the chain of dependent
+    // instructions behind them -- two WG_SUM trees, a reciprocal, two divisions -- so FOUR rows are taken through
+    // that chain together (independent chains interleave), the next four already requested.  Per row the arithmetic
+    // is consume()'s (the non-link sign as an exact multiplication by -1, as in update_phi_lds2_kernel) and the
+    // gradient accumulates row by row in order: bit-identical.
+    bool batched = false;
+    if constexpr (KPT <= 2 && DEPTH == 4) {
+      if (n % 4 == 0) {
+        batched = true;
+        float nxt[4][KPT];
+        auto consume4 = [&](float (&pin)[4][KPT], uint32_t q0) {
+          float ee[4], sg[4], part[4], lo[4], psum[4];
+          bool fast[4], all_fast = true;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool y = (s_nb[q0 + r] >> 31) != 0;
+            ee[r] = y ? EPS : 1.0f - EPS;
+            sg[r] = y ? 1.0f : -1.0f;
+            part[r] = 0.0f;
+            lo[r] = 1.0f;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+              const float tt = (pin[r][j] * bf[j]) * sg[r] + ee[r];
+              pin[r][j] = pi_a[j] * tt;
+              part[r] += pin[r][j];
+              lo[r] = fminf(lo[r], has(j) ? fabsf(pin[r][j]) : 1.0f);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            psum[r] = Grp::sum(part[r], aux, phase);
+            fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
+            all_fast = all_fast && fast[r];
+          }
+          if (all_fast) {
+            float rps[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rps[r] = refined_rcp(psum[r]);
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+              float qv[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                qv[r] = div_with_rcp(pin[r][j], psum[r], rps[r]);
+                qv[r] = div_with_rcp(qv[r], pi_a[j] * phi_sum, rden[j]);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) grads[j] += qv[r] - inv_phi_sum;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (fast[r]) {
+                const float rps = refined_rcp(psum[r]);
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) {
+                  float qv = div_with_rcp(pin[r][j], psum[r], rps);
+                  qv = div_with_rcp(qv, pi_a[j] * phi_sum, rden[j]);
+                  grads[j] += qv - inv_phi_sum;
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) {
+                  float qv = pin[r][j] / psum[r];
+                  qv = qv / (pi_a[j] * phi_sum);
+                  grads[j] += qv - inv_phi_sum;
+                }
+              }
+            }
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < 4; ++d) load_row(buf[d], d);
+        for (uint32_t q0 = 0; q0 < n; q0 += 4) {
+          if (q0 + 4 < n) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) load_row(nxt[d], q0 + 4 + d);
+          }
+          consume4(buf, q0);
+          if (q0 + 4 < n) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+              for (int j = 0; j < KPT; ++j) buf[d][j] = nxt[d][j];
+          }
+        }
+      }
+    }
+
     // Software pipeline, DEPTH-1 rows ahead.  The steady state is straight-line code (no branch around
     // a load): hipcc's wait-count insertion falls back to vmcnt(0) -- draining the rows just requested
     // -- when paths with different numbers of outstanding loads meet.  n = G*DEPTH + r rows: the first
     // G-1 groups request and consume DEPTH rows each, the last group requests only its last row, the r
     // left-over rows are handled one at a time.
-    const uint32_t groups = n / DEPTH;
+    const uint32_t groups = batched ? 0 : n / DEPTH;
     if (groups > 0) {
 #pragma unroll
       for (int d = 0; d < DEPTH - 1; ++d) load_row(buf[d], d);
@@ -222,7 +311,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) consume(buf[d], q0 + d);
     }
-    for (uint32_t q = groups * DEPTH; q < n; ++q) {
+    for (uint32_t q = batched ? n : groups * DEPTH; q < n; ++q) {
       load_row(buf[0], q);
       consume(buf[0], q);
     }
