@@ -739,6 +739,168 @@ __global__ void beta_from_theta_kernel(const float* theta, float* beta, uint32_t
   beta[2 * k + 1] = t1 / lsum;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Generic form: any K <= 1024 * (blockDim.x / 64), any power-of-two reference work-group size L <= blockDim.x / 2.
+//
+// The reference's per-work-group kernel loops K_PER_THREAD = ceil(K / L) columns per work-item generically
+// (beta.cc:145-233) and its default beta_wg_size is 32 (main.cc:64): K = 1024 means 32 columns, K = 4096 means 128
+// columns per work-item -- more than a lane's registers hold next to the 2 K / L accumulators.  As in
+// update_phi_gen_kernel (ammsb_phi.hip) the elementwise work of a slot is spread over all T = blockDim.x threads
+// (thread t owns columns t + T i) independently of L, and the two WG_SUMs of an edge (beta.cc:209-217) are emulated
+// lane by lane with the reference's association order (vgroup_sum<2>, ammsb_dev.h).  The slot -> edge assignment, the
+// per-column accumulation order and every operation are those of beta_grads_kernel<L, KPT>: the partial rows are
+// bit-identical to it wherever both run.
+template <int CPT>
+__global__ __launch_bounds__(512) void beta_grads_gen_kernel(const BetaArgs a, uint32_t L, uint32_t lgL) {
+  extern __shared__ __align__(16) char smem[];  // [K] f, [K] probs, [2 L] lane partials, [4] sums, [64] keys, [64] links
+  const uint32_t K = a.K, T = blockDim.x, t = threadIdx.x;
+  float* s_f = reinterpret_cast<float*>(smem);
+  float* s_p = s_f + K;
+  float* s_aux = s_p + K;
+  float* s_res = s_aux + 2 * L;
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_res + 4);
+  uint32_t* s_link = reinterpret_cast<uint32_t*>(s_key + 64);
+  const BetaStep st = beta_step(a);
+  const uint32_t gs = blockIdx.x;  // partial-row slot
+  if (gs >= st.P) return;          // block-uniform
+  const float EPS = a.epsilon;
+
+  auto col = [&](int j) -> uint32_t { return t + (uint32_t)j * T; };
+  auto has = [&](int j) -> bool { return t + (uint32_t)j * T < K; };
+
+  float bk[CPT], d0n[CPT], d1l[CPT], noo[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const uint32_t k = col(j);
+    if (k < K) {
+      const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
+      const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
+      if (gs == 0) a.theta_sum[k] = ts;
+      const float oo = 1.0f / ts;
+      bk[j] = a.beta[2 * k + 1];
+      d0n[j] = 1.0f / t0 - oo;
+      d1l[j] = 1.0f / t1 - oo;
+      noo[j] = 0.0f - oo;
+    } else {
+      bk[j] = d0n[j] = d1l[j] = noo[j] = 0.0f;
+    }
+  }
+  float acc0[CPT], acc1[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) acc0[j] = acc1[j] = 0.0f;
+
+  // edges of this slot: e(r) = edge_begin + gs + r * P, r < trips
+  const uint32_t n_edges = st.edge_end - st.edge_begin;
+  const uint32_t trips = gs < n_edges ? (n_edges - gs + st.P - 1) / st.P : 0;  // block-uniform
+  int phase = 0;
+  float pa[CPT], pb[CPT], na[CPT], nb[CPT];
+  auto load_rows = [&](float (&da)[CPT], float (&db)[CPT], uint32_t slot) {
+    const unsigned long long edge = s_key[slot];
+    const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(edge >> 32));
+    const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)(edge & 0xffffffffu));
+    const float* ra = rpm_row(a.pi, u);
+    const float* rb = rpm_row(a.pi, v);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const uint32_t k = col(j), ck = k < K ? k : K - 1;
+      da[j] = ra[ck];
+      db[j] = rb[ck];
+    }
+  };
+
+  for (uint32_t tb = 0; tb < trips; tb += 64) {
+    // keys and link bits of the next 64 trips: one probe per thread of the first wave
+    __syncthreads();
+    if (t < 64) {
+      const bool ok = tb + t < trips;
+      const uint64_t e = (uint64_t)st.edge_begin + gs + (uint64_t)(tb + t) * st.P;
+      const unsigned long long edge = a.edges[ok ? e : (uint64_t)st.edge_begin + gs];
+      const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
+      s_key[t] = edge;
+      s_link[t] = set_has(a.set, make_edge(u, v)) ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t cnt = trips - tb < 64u ? trips - tb : 64u;
+    load_rows(pa, pb, 0);
+    for (uint32_t r = 0; r < cnt; ++r) {
+      load_rows(na, nb, r + 1 < cnt ? r + 1 : r);  // unconditional: the last trip of a batch re-requests its own rows
+      const bool y = __builtin_amdgcn_readfirstlane(s_link[r]) != 0;
+      float probs[CPT];
+      float lo = 1.0f;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {  // CALC_PROBS, beta.cc:145-160
+        const float f = (has(j) ? pa[j] : 0.0f) * pb[j];
+        probs[j] = y ? bk[j] * f : (1.0f - bk[j]) * f;
+        if (has(j)) {
+          s_f[col(j)] = f;
+          s_p[col(j)] = probs[j];
+        }
+        const float m = fabsf(probs[j]);
+        lo = fminf(lo, m == 0.0f ? 1.0f : m);
+      }
+      __syncthreads();
+      const float* const vv[2] = {s_f, s_p};
+      float sums[2];
+      vgroup_sum<2>(vv, K, L, lgL, s_aux, s_res, phase, sums);  // beta.cc:209-217
+      const float pi_sum = sums[0];
+      float probs_sum = sums[1];
+      const float w = y ? EPS : (1.0f - EPS);
+      const float prob_0 = w * (1.0f - pi_sum);
+      probs_sum += prob_0;
+      // CALC_GRADS, beta.cc:161-171
+      if (lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+        const float rps = refined_rcp(probs_sum);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          const float f = div_with_rcp(probs[j], probs_sum, rps);
+          acc0[j] += f * (y ? noo[j] : d0n[j]);
+          acc1[j] += f * (y ? d1l[j] : noo[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          const float f = probs[j] / probs_sum;
+          acc0[j] += f * (y ? noo[j] : d0n[j]);
+          acc1[j] += f * (y ? d1l[j] : noo[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        pa[j] = na[j];
+        pb[j] = nb[j];
+      }
+    }
+  }
+
+  float* out = a.partials + (uint64_t)gs * 2 * K;
+#pragma unroll
+  for (int j = 0; j < CPT; ++j)
+    if (has(j)) *reinterpret_cast<float2*>(out + 2 * col(j)) = make_float2(acc0[j], acc1[j]);
+}
+
+constexpr uint32_t kGenMaxK = 8192;  // 512 threads x 16 columns
+inline int gen_cpt(uint64_t K) { return K <= 4096 ? 8 : 16; }  // columns per thread (as in ammsb_phi.hip)
+
+// threads per block: enough for the columns and two virtual lanes' worth of chains; 0 if the shape does not fit
+inline uint32_t gen_threads(uint64_t K, uint32_t L) {
+  if (K > kGenMaxK) return 0;
+  const uint32_t per_wave = 64u * (uint32_t)gen_cpt(K);
+  uint32_t T = 64u * (uint32_t)((K + per_wave - 1) / per_wave);
+  if (T < 2 * L) T = 2 * L;
+  if (T < 64) T = 64;
+  return T <= 512 ? T : 0;
+}
+
+int launch_grads_gen(ammsb_ctx* ctx, const BetaArgs& a, uint32_t wg, hipStream_t s) {
+  const uint32_t T = gen_threads(a.K, wg);
+  if (!T) return AMMSB_ERANGE;
+  const size_t lds = sizeof(float) * (2 * (size_t)a.K + 2 * wg + 4) + 64 * (sizeof(unsigned long long) + sizeof(uint32_t));
+  if (gen_cpt(a.K) == 8) beta_grads_gen_kernel<8><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  else beta_grads_gen_kernel<16><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 template <int L, int KPT>
 int launch_grads(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   using Grp = Group<L>;
@@ -829,8 +991,15 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
     return AMMSB_OK;
   }
   const int kpt = pick_kpt(K, wg);
-  if (kpt == 0) {
-    snprintf(ctx->err, sizeof ctx->err, "ammsb_beta_grads: K=%u needs wg >= %u", K, (K + 15) / 16);
+  // AMMSB_BETA_FORM=g: the generic kernel wherever it fits (tests compare it with the specialised ones)
+  static const bool force_gen = [] {
+    const char* f = getenv("AMMSB_BETA_FORM");
+    return f && f[0] == 'g';
+  }();
+  const bool generic = kpt == 0 || (force_gen && gen_threads(K, wg) != 0 && !(fuse && fuse->phi_vec));
+  if (generic && gen_threads(K, wg) == 0) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_beta_grads: K=%u at wg=%u: more than 16 columns per work-item needs K <= %u",
+             K, wg, kGenMaxK);
     return AMMSB_ERANGE;
   }
   BetaArgs a;
@@ -869,7 +1038,10 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   // lane for longer rows (K = 4096: wg 256)
   bool launched = false;
   int rc = AMMSB_OK;
-  if (!force_reg && K == wg * (uint32_t)kpt && pi->num_cols % 4 == 0) {
+  if (generic) {
+    launched = true;
+    rc = launch_grads_gen(ctx, a, wg, s);
+  } else if (!force_reg && K == wg * (uint32_t)kpt && pi->num_cols % 4 == 0) {
     launched = true;
     if (wg == 64 && kpt == 4) rc = launch_grads_lds<4, 1>(ctx, a, s);
     else if (wg == 64 && kpt == 8) rc = launch_grads_lds<8, 1>(ctx, a, s);

@@ -330,4 +330,63 @@ struct Group {
 
 inline __host__ __device__ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
+// ----------------------------------------------------------------- virtual group sum (any K / L)
+// The generic kernels (the shapes no specialised kernel takes: more columns per reference work-item than fit a lane's
+// registers -- K = 1024 at the reference's default work-group size 32 for the gradient, K = 4096 at 32 for all three)
+// spread the ELEMENTWISE work of a virtual group over all T = blockDim.x threads of a block (thread t owns columns
+// t, t + T, ...) whatever the reference work-group size L is.  Only what depends on L is emulated lane by lane: the
+// association order of WG_SUM -- virtual lane l < L chains vals[l], vals[l + L], ... in ascending order
+// (sum.cc:20-22), then the halving tree aux[l] += aux[l + p2] over the L lane partials (sum.cc:23-29) -- and the
+// stream-to-column map of the noise (in the kernels).  N sums at once: chain i runs on threads [i L, (i + 1) L).
+//
+// Block-uniform; needs N L <= T (and T >= 64 N when L > 64), vals[] visible to the block (barrier before the call);
+// aux: [N L] floats of LDS, res: [2 N] floats of LDS (double-buffered through `phase`).  On return every thread holds
+// the N sums and vals[] may be overwritten.
+template <int N>
+__device__ __forceinline__ void vgroup_sum(const float* const (&vals)[N], uint32_t K, uint32_t L, uint32_t lgL,
+                                           float* aux, float* res, int& phase, float (&out)[N]) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t which = t >> lgL, vl = t & (L - 1);
+  float s = 0.0f;
+  if (which < (uint32_t)N) {
+    const float* v = vals[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = which == (uint32_t)i ? vals[i] : v;
+    for (uint32_t k = vl; k < K; k += L) s += v[k];
+  }
+  float* r = res + phase * N;
+  phase ^= 1;
+  if (L > 64) {
+    if (which < (uint32_t)N) aux[t] = s;  // which * L + vl == t
+    __syncthreads();
+    for (uint32_t lp = lgL - 1; lp >= 6; --lp) {  // p2 = L/2 .. 64
+      const uint32_t p2 = 1u << lp, h = t >> lp, l = t & (p2 - 1);
+      if (h < (uint32_t)N) aux[h * L + l] += aux[h * L + l + p2];
+      __syncthreads();
+    }
+    const uint32_t w = t >> 6;  // wave w finishes sum w from its 64 remaining partials
+    s = w < (uint32_t)N ? aux[w * L + (t & 63)] : 0.0f;
+#pragma unroll
+    for (int p2 = 32; p2 > 0; p2 >>= 1) s += __shfl_xor(s, p2, 64);
+    if (w < (uint32_t)N && (t & 63) == 0) r[w] = s;
+  } else {
+    // L <= 64: chain i sits in the aligned L-lane block [i L, (i + 1) L) of one wave; a + b == b + a bitwise, so the
+    // XOR butterfly leaves the tree's root in every lane of the block (Group<L>::wave_tree)
+    for (uint32_t p2 = L >> 1; p2 > 0; p2 >>= 1) s += __shfl_xor(s, (int)p2, 64);
+    if (which < (uint32_t)N && vl == 0) r[which] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = r[i];
+}
+
+__host__ __device__ inline uint32_t ilog2_u32(uint32_t v) {
+  uint32_t r = 0;
+  while (v > 1) {
+    v >>= 1;
+    ++r;
+  }
+  return r;
+}
+
 }  // namespace ammsb

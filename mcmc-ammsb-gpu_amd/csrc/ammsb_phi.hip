@@ -957,6 +957,221 @@ int launch_pi(ammsb_ctx* ctx, const ammsb_rpm& pi, float* phi_sum, const float* 
   return AMMSB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Generic form: any K <= 1024 * (blockDim.x / 64), any power-of-two reference work-group size L <= blockDim.x.
+//
+// The reference loops K_PER_THREAD = ceil(K / L) columns per work-item generically (phi.cc:214-302), so e.g. its
+// default phi_wg_size = 32 (main.cc:61) is valid at K = 4096: 128 columns per work-item, which no register- or
+// LDS-resident per-lane layout above holds.  Here the elementwise work of a node is spread over all T = blockDim.x
+// threads (thread t owns columns t + T i, at most CPT of them) independently of L; what L fixes -- the WG_SUM
+// association order and which stream draws the noise of which column -- is emulated lane by lane: vgroup_sum()
+// (ammsb_dev.h) for the sum, and for the noise thread l < L owns stream g L + l and draws for columns l, l + L, ...
+// in ascending order (phi.cc:266-274, 291, 300).  Same operations in the same order on every value as
+// update_phi_kernel<L, KPT>: bit-identical to it (and to the oracle) wherever both run.
+template <int CPT>
+__global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, uint32_t L, uint32_t lgL) {
+  extern __shared__ __align__(16) char smem[];  // [K] probs / noise, [L] lane partials, [2] sums, [n] u32
+  __shared__ ZigTables zig;
+  const uint32_t K = a.K, n = a.n, T = blockDim.x, t = threadIdx.x;
+  float* s_vals = reinterpret_cast<float*>(smem);
+  float* s_aux = s_vals + K;
+  float* s_res = s_aux + L;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(s_res + 2);
+
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, 0);
+  const uint32_t g = a.group_begin + blockIdx.x;
+  if (g >= st.group_end) return;  // block-uniform
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  auto col = [&](int j) -> uint32_t { return t + (uint32_t)j * T; };
+  auto ccol = [&](int j) -> uint32_t {
+    const uint32_t k = t + (uint32_t)j * T;
+    return k < K ? k : K - 1;
+  };
+  auto has = [&](int j) -> bool { return t + (uint32_t)j * T < K; };
+
+  float bf[CPT];
+  bool beta_safe = true;
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const float b = a.beta[2 * ccol(j) + 1];
+    bf[j] = b - EPS;
+    beta_safe = beta_safe && in_range(b, EPS, kBetaHi);
+  }
+  ammsb_seed rs = {0, 0};
+  if (a.noise_on && t < L) rs = a.seeds[(uint64_t)g * L + t];  // rand->base_[GET_GLOBAL_ID()], phi.cc:291
+
+  int phase = 0;
+  for (uint64_t i = g; i < st.n_nodes; i += st.G) {
+    const uint32_t node = a.nodes[i];
+    __syncthreads();  // orders the LDS traffic of consecutive nodes
+    for (uint32_t q = t; q < n; q += T) {
+      const uint32_t nbq = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nbq));
+      s_nb[q] = nbq | (y ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+
+    const float phi_sum = a.phi_sum[node];
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = rpm_row(a.pi, node);
+    float pi_a[CPT], grads[CPT], rden[CPT];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const float x = row_a[ccol(j)];
+      pi_a[j] = has(j) ? x : 0.0f;
+      grads[j] = 0.0f;
+      const float den = pi_a[j] * phi_sum;
+      rden[j] = exact_rcp(den);
+      node_safe = node_safe && (in_range(den, kDenLo, kDenHi) || !has(j));
+    }
+
+    float cur[CPT], nxt[CPT];
+    auto load_row = [&](float (&dst)[CPT], uint32_t q) {
+      const uint32_t w = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
+      const float* row = rpm_row(a.pi, w);
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) dst[j] = row[ccol(j)];
+    };
+    if (n > 0) load_row(cur, 0);
+    for (uint32_t q = 0; q < n; ++q) {
+      load_row(nxt, q + 1 < n ? q + 1 : q);  // unconditional: the last trip re-requests its own row
+      const bool y = __builtin_amdgcn_readfirstlane(s_nb[q] >> 31) != 0;
+      const float e = y ? EPS : 1.0f - EPS;
+      float pr[CPT];
+      float lo = 1.0f;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {  // phi.cc:241-253
+        const float tt0 = cur[j] * bf[j];
+        const float tt = y ? tt0 + e : e - tt0;
+        pr[j] = pi_a[j] * tt;
+        if (has(j)) s_vals[col(j)] = pr[j];
+        lo = fminf(lo, has(j) ? fabsf(pr[j]) : 1.0f);
+      }
+      __syncthreads();
+      const float* const vv[1] = {s_vals};
+      float sums[1];
+      vgroup_sum<1>(vv, K, L, lgL, s_aux, s_res, phase, sums);  // phi.cc:254-257
+      const float probs_sum = sums[0];
+      // phi.cc:259-263: grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
+      if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+        const float rps = exact_rcp(probs_sum);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          float qv = div_exact3(pr[j], probs_sum, rps);
+          qv = div_exact3(qv, pi_a[j] * phi_sum, rden[j]);
+          grads[j] += qv - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          float qv = pr[j] / probs_sum;
+          qv = qv / (pi_a[j] * phi_sum);
+          grads[j] += qv - inv_phi_sum;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) cur[j] = nxt[j];
+    }
+
+    // the noise of column k comes from stream g L + (k mod L), drawn in ascending k (phi.cc:266-274)
+    if (a.noise_on) {
+      if (t < L)
+        for (uint32_t k = t; k < K; k += L) s_vals[k] = rng_normal(rs, &zig);
+      __syncthreads();
+    }
+    // SGLD step, phi.cc:265-274
+    float* out = a.phi_vec + i * K;
+    const float half = st.eps_t / 2;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      if (has(j)) {
+        const float noise = a.noise_on ? s_vals[col(j)] : 1.0f;
+        const float phi_k = pi_a[j] * phi_sum;
+        const float ng = a.Nn * grads[j];
+        float in = a.alpha - phi_k;
+        in = in + ng;
+        const float drift = half * in;
+        const float aa = phi_k + drift;
+        const float ep = st.eps_t * phi_k;
+        const float sq = sqrtf(ep);
+        const float bb = sq * noise;
+        const float v = fabsf(aa + bb);
+        out[col(j)] = v > 1e-24f ? v : 1e-24f;
+      }
+    }
+  }
+  if (a.noise_on && t < L) a.seeds[(uint64_t)g * L + t] = rs;
+}
+
+// update_pi for the same shapes (phi.cc:177-197): one block per node, elementwise over all threads, WG_SUM emulated
+template <int CPT>
+__global__ __launch_bounds__(512) void update_pi_gen_kernel(ammsb_rpm pi, float* phi_sum, const float* phi_vec,
+                                                             const uint32_t* nodes, uint32_t n_nodes, uint32_t K,
+                                                             uint32_t L, uint32_t lgL, const ammsb_step_desc* desc,
+                                                             unsigned long long* stamps) {
+  extern __shared__ __align__(16) char smem[];  // [K] values, [L] lane partials, [2] sums
+  float* s_vals = reinterpret_cast<float*>(smem);
+  float* s_aux = s_vals + K;
+  float* s_res = s_aux + L;
+  if (desc) n_nodes = desc->n_nodes;
+  note_stamp(stamps, desc, 1);
+  const uint64_t i = blockIdx.x;
+  if (i >= n_nodes) return;  // block-uniform
+  const uint32_t T = blockDim.x, t = threadIdx.x;
+  const float* src = phi_vec + i * K;
+  float v[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const uint32_t k = t + (uint32_t)j * T;
+    v[j] = k < K ? src[k] : 0.0f;
+    if (k < K) s_vals[k] = v[j];
+  }
+  __syncthreads();
+  int phase = 0;
+  const float* const vv[1] = {s_vals};
+  float sums[1];
+  vgroup_sum<1>(vv, K, L, lgL, s_aux, s_res, phase, sums);
+  const float sum = sums[0];
+  const uint32_t node = nodes[i];
+  float* row = rpm_row(pi, node);
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const uint32_t k = t + (uint32_t)j * T;
+    if (k < K) row[k] = v[j] / sum;
+  }
+  if (t == 0) phi_sum[node] = sum;
+}
+
+constexpr uint32_t kGenMaxK = 8192;  // 512 threads x 16 columns
+
+// columns per thread of the generic kernels: 8 up to K = 4096 (more threads per node, no register pressure), 16 above
+inline int gen_cpt(uint64_t K) { return K <= 4096 ? 8 : 16; }
+
+// threads per block of a generic kernel running `sums` concurrent WG_SUM chains: enough for the columns, and at least
+// sums * L so that every virtual lane has a thread; 0 if the shape does not fit a 512-thread block
+inline uint32_t gen_threads(uint64_t K, uint32_t L, uint32_t sums) {
+  if (K > kGenMaxK) return 0;
+  const uint32_t per_wave = 64u * (uint32_t)gen_cpt(K);
+  uint32_t T = 64u * (uint32_t)((K + per_wave - 1) / per_wave);
+  if (T < sums * L) T = sums * L;
+  if (T < 64) T = 64;
+  return T <= 512 ? T : 0;
+}
+
+int launch_phi_gen(ammsb_ctx* ctx, const PhiArgs& a, uint32_t wg, uint32_t n_groups, hipStream_t s) {
+  const uint32_t T = gen_threads(a.K, wg, 1);
+  if (!T) return AMMSB_ERANGE;
+  const size_t lds = sizeof(float) * ((size_t)a.K + wg + 2) + sizeof(uint32_t) * a.n;
+  if (gen_cpt(a.K) == 8) update_phi_gen_kernel<8><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  else update_phi_gen_kernel<16><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 // smallest instantiated KPT >= ceil(K / L), or 0 if K is too long for this work-group size
 inline int pick_kpt(uint64_t K, uint32_t L) {
   const uint64_t need = (K + L - 1) / L;
@@ -1007,9 +1222,15 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   AMMSB_CHECK_ARG(ctx, is_pow2(wg) && wg >= 16 && wg <= 1024, "phi wg must be a power of two in [16, 1024]");
   const ammsb_params& p = ctx->params;
   const int kpt = pick_kpt(p.K, wg);
-  if (kpt == 0) {
-    snprintf(ctx->err, sizeof ctx->err, "ammsb_update_phi: K=%llu needs wg >= %llu", (unsigned long long)p.K,
-             (unsigned long long)((p.K + 31) / 32));
+  // AMMSB_PHI_FORM=g: the generic kernel wherever it fits (tests compare it with the specialised ones)
+  static const bool force_gen = [] {
+    const char* f = getenv("AMMSB_PHI_FORM");
+    return f && f[0] == 'g';
+  }();
+  const bool generic = kpt == 0 || (force_gen && gen_threads(p.K, wg, 1) != 0);
+  if (generic && gen_threads(p.K, wg, 1) == 0) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_update_phi: K=%llu at wg=%u: more than 32 columns per work-item needs K <= %u",
+             (unsigned long long)p.K, wg, kGenMaxK);
     return AMMSB_ERANGE;
   }
   PhiArgs a;
@@ -1037,6 +1258,7 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   if (a.group_begin >= a.group_end) return AMMSB_OK;
   const uint32_t n_groups = a.group_end - a.group_begin;
   hipStream_t s = as_stream(stream);
+  if (generic) return launch_phi_gen(ctx, a, wg, n_groups, s);
   static const bool force_reg = [] {
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
@@ -1146,9 +1368,27 @@ static int update_pi_common(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum,
   AMMSB_CHECK_ARG(ctx, is_pow2(wg) && wg >= 16 && wg <= 1024, "phi wg must be a power of two in [16, 1024]");
   if (n_nodes == 0) return AMMSB_OK;
   const int kpt = pick_kpt(ctx->params.K, wg);
-  if (kpt == 0) return AMMSB_ERANGE;
   const uint32_t K = (uint32_t)ctx->params.K;
   hipStream_t s = as_stream(stream);
+  static const bool force_gen = [] {
+    const char* f = getenv("AMMSB_PHI_FORM");
+    return f && f[0] == 'g';
+  }();
+  if (kpt == 0 || (force_gen && gen_threads(K, wg, 1) != 0)) {
+    const uint32_t T = gen_threads(K, wg, 1);
+    if (!T) {
+      snprintf(ctx->err, sizeof ctx->err, "ammsb_update_pi: K=%u at wg=%u: more than 32 columns per work-item needs K <= %u",
+               K, wg, kGenMaxK);
+      return AMMSB_ERANGE;
+    }
+    const size_t lds = sizeof(float) * ((size_t)K + wg + 2);
+    if (gen_cpt(K) == 8)
+      update_pi_gen_kernel<8><<<n_nodes, T, lds, s>>>(*pi, phi_sum, phi_vec, nodes, n_nodes, K, wg, ilog2_u32(wg), desc, stamps);
+    else
+      update_pi_gen_kernel<16><<<n_nodes, T, lds, s>>>(*pi, phi_sum, phi_vec, nodes, n_nodes, K, wg, ilog2_u32(wg), desc, stamps);
+    AMMSB_LAUNCH_CHECK(ctx);
+    return AMMSB_OK;
+  }
   AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, return (launch_pi<L_, KPT_>(ctx, *pi, phi_sum, phi_vec, nodes,
                                                                                 n_nodes, K, desc, stamps, s))));
   return AMMSB_OK;

@@ -259,6 +259,129 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Generic form: any K <= 1024 * (blockDim.x / 64), any power-of-two reference work-group size L <= blockDim.x / 2
+// (the reference's ppx_wg_size defaults to 32, main.cc:63; at K = 4096 that is 128 columns per work-item,
+// perplexity.cc:93-157).  Elementwise work over all T = blockDim.x threads, the two WG_SUMs emulated lane by lane with
+// the reference's association order (vgroup_sum<2>, ammsb_dev.h); slot -> edge assignment, the per-slot accumulation
+// order and every operation are ppx_kernel<L, KPT>'s: bit-identical to it wherever both run.
+template <int CPT>
+__global__ __launch_bounds__(512) void ppx_gen_kernel(const PpxArgs a, uint32_t L, uint32_t lgL) {
+  extern __shared__ __align__(16) char smem[];  // [K] f, [K] weighted f, [2 L] lane partials, [4] sums
+  const uint32_t K = a.K, T = blockDim.x, t = threadIdx.x;
+  float* s_f = reinterpret_cast<float*>(smem);
+  float* s_w = s_f + K;
+  float* s_aux = s_w + K;
+  float* s_res = s_aux + 2 * L;
+  const uint32_t gs = blockIdx.x;  // the grid is exactly P blocks
+
+  auto col = [&](int j) -> uint32_t { return t + (uint32_t)j * T; };
+  auto has = [&](int j) -> bool { return t + (uint32_t)j * T < K; };
+  float bk[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) bk[j] = has(j) ? a.beta[2 * col(j) + 1] : 0.0f;
+
+  double ll_link = 0.0, ll_non = 0.0;
+  unsigned long long c_link = 0, c_non = 0;
+  const uint32_t n_edges = a.edge_end - a.edge_begin;
+  const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // block-uniform
+  int phase = 0;
+  const float cm1 = (float)(a.call_count - 1), cc = (float)a.call_count;
+
+  float pa[CPT], pb[CPT], na[CPT], nb[CPT];
+  auto load_rows = [&](float (&da)[CPT], float (&db)[CPT], uint32_t r) -> unsigned long long {
+    const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)r * a.P;
+    const unsigned long long key = a.edges[e];  // used as stored: no canonicalisation (perplexity.cc:45-47)
+    const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(key >> 32));
+    const uint32_t v = __builtin_amdgcn_readfirstlane((uint32_t)(key & 0xffffffffu));
+    const float* ra = rpm_row(a.pi, u);
+    const float* rb = rpm_row(a.pi, v);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const uint32_t k = col(j), ck = k < K ? k : K - 1;
+      da[j] = __builtin_nontemporal_load(ra + ck);
+      db[j] = __builtin_nontemporal_load(rb + ck);
+    }
+    return key;
+  };
+  unsigned long long key = 0, nkey = 0;
+  if (trips > 0) key = load_rows(pa, pb, 0);
+  for (uint32_t r = 0; r < trips; ++r) {
+    nkey = load_rows(na, nb, r + 1 < trips ? r + 1 : r);  // unconditional: the last trip re-requests its own rows
+    const bool y = set_has(a.set, key);                   // block-uniform (every thread probes the same key)
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {  // perplexity.cc:100-119
+      const float f = (has(j) ? pa[j] : 0.0f) * pb[j];
+      if (has(j)) {
+        s_f[col(j)] = f;
+        s_w[col(j)] = f * (y ? bk[j] : 1.0f - bk[j]);
+      }
+    }
+    __syncthreads();
+    const float* const vv[2] = {s_f, s_w};
+    float sums[2];
+    vgroup_sum<2>(vv, K, L, lgL, s_aux, s_res, phase, sums);
+    const float fsum = sums[0];
+    float s = sums[1];
+    if (!y) {
+      const float tt = 1.0f - fsum;
+      const float u1 = 1.0f - a.epsilon;
+      s += tt * u1;
+    }
+    if (s < 1.0e-30f) s = 1.0e-30f;
+    if (t == 0) {  // perplexity.cc:139-156
+      const uint64_t pos = (uint64_t)a.edge_begin + gs + (uint64_t)r * a.P;
+      float ppx = a.ppx_per_edge[pos];
+      float m = ppx * cm1;
+      m = m + s;
+      ppx = m / cc;
+      const float ll = logf_cr(ppx);
+      if (y) {
+        c_link += 1;
+        ll_link += (double)ll;
+      } else {
+        c_non += 1;
+        ll_non += (double)ll;
+      }
+      a.ppx_per_edge[pos] = ppx;
+    }
+    key = nkey;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      pa[j] = na[j];
+      pb[j] = nb[j];
+    }
+  }
+  if (t == 0) {
+    a.ll_partials[2 * gs] = ll_link;
+    a.ll_partials[2 * gs + 1] = ll_non;
+    a.cnt_partials[2 * gs] = c_link;
+    a.cnt_partials[2 * gs + 1] = c_non;
+  }
+}
+
+constexpr uint32_t kGenMaxK = 8192;  // 512 threads x 16 columns
+inline int gen_cpt(uint64_t K) { return K <= 4096 ? 8 : 16; }  // columns per thread (as in ammsb_phi.hip)
+
+inline uint32_t gen_threads(uint64_t K, uint32_t L) {
+  if (K > kGenMaxK) return 0;
+  const uint32_t per_wave = 64u * (uint32_t)gen_cpt(K);
+  uint32_t T = 64u * (uint32_t)((K + per_wave - 1) / per_wave);
+  if (T < 2 * L) T = 2 * L;
+  if (T < 64) T = 64;
+  return T <= 512 ? T : 0;
+}
+
+int launch_ppx_gen(ammsb_ctx* ctx, const PpxArgs& a, uint32_t wg, hipStream_t s) {
+  const uint32_t T = gen_threads(a.K, wg);
+  if (!T) return AMMSB_ERANGE;
+  const size_t lds = sizeof(float) * (2 * (size_t)a.K + 2 * wg + 4);
+  if (gen_cpt(a.K) == 8) ppx_gen_kernel<8><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  else ppx_gen_kernel<16><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 template <int KPT>
 int launch_ppx_lds(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
   // two-edge ring: 16 KiB per wave, so the 8 slots per CU the launch asks for are resident at once (a three-edge
@@ -366,8 +489,15 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
   }
   const uint32_t K = (uint32_t)ctx->params.K;
   const int kpt = pick_kpt(K, wg);
-  if (kpt == 0) {
-    snprintf(ctx->err, sizeof ctx->err, "ammsb_perplexity: K=%u needs wg >= %u", K, (K + 31) / 32);
+  // AMMSB_PPX_FORM=g: the generic kernel wherever it fits (tests compare it with the specialised ones)
+  static const bool force_gen = [] {
+    const char* f = getenv("AMMSB_PPX_FORM");
+    return f && f[0] == 'g';
+  }();
+  const bool generic = kpt == 0 || (force_gen && gen_threads(K, wg) != 0);
+  if (generic && gen_threads(K, wg) == 0) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_perplexity: K=%u at wg=%u: more than 32 columns per work-item needs K <= %u",
+             K, wg, kGenMaxK);
     return AMMSB_ERANGE;
   }
   PpxArgs a;
@@ -392,7 +522,10 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
     const char* f = getenv("AMMSB_PPX_FORM");
     return f && f[0] == 'r';
   }();
-  if (wg == 64 && !force_reg && K == 64u * (uint32_t)kpt && kpt >= 4 && kpt <= 16 && pi->num_cols % 4 == 0) {
+  if (generic) {
+    const int rc = launch_ppx_gen(ctx, a, wg, s);
+    if (rc) return rc;
+  } else if (wg == 64 && !force_reg && K == 64u * (uint32_t)kpt && kpt >= 4 && kpt <= 16 && pi->num_cols % 4 == 0) {
     int rc = AMMSB_OK;
     switch (kpt) {
       case 4: rc = launch_ppx_lds<4>(ctx, a, s); break;

@@ -122,3 +122,22 @@ def test_cli_run_load_and_resume(exe, tmp_path):
     c = subprocess.run([exe] + load + common + ["-x", "100", "-i", "100", "--checkpoint-in", ck], capture_output=True,
                        text=True, timeout=600)
     assert _ppx_lines(b.stderr) == _ppx_lines(c.stderr) and len(_ppx_lines(b.stderr)) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loop", [[], ["--async", "1", "--device-sampling", "1"], ["--graph", "1", "--device-sampling", "1"]])
+def test_cli_reference_default_work_groups_at_k1024(exe, tmp_path, loop):
+    """`ammsb_main -k 1024 -m 4096` with NO work-group flags: the reference's defaults are 32 for phi, beta, perplexity
+    and the neighbour sampler (main.cc:61-64), i.e. 32 columns per work-item at K = 1024 -- the generic gradient
+    kernel and the 32-column register form of update_phi / perplexity.  Must run, learn and print every category."""
+    g, d = str(tmp_path / "g.txt"), str(tmp_path / "g.bin.gz")
+    _snap_file(g, N=6000, deg=16)
+    r = subprocess.run([exe, "-f", g, "--dump-data", "1", "--dump-file", d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([exe, "--load-data", "1", "--load-file", d, "-k", "1024", "-m", "4096", "-x", "40", "-i", "20"]
+                         + loop, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    ppx = _ppx_lines(run.stderr)
+    assert [s for s, _ in ppx] == [0, 20, 40]
+    assert all(np.isfinite(p) and p > 1.0 for _, p in ppx)
+    assert re.search(r"^TOTAL *:", run.stderr, re.M)

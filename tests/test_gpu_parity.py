@@ -290,6 +290,11 @@ PHI_CASES = [
     (300, 8192, 3, 6, 512),     # 8 waves per node
     (3000, 4096, 33, 70, 256),  # more neighbours than one key batch row, odd n
     (4096, 512, 4, 4096, 32),   # wg-phi-test.cc:116-142 shape (N=4096, K=512, n=4, all nodes)
+    (1024, 1024, 32, 64, 32),   # the C3 row shape at the reference's default phi_wg_size (main.cc:61): 32 columns per lane
+    (512, 4096, 4, 16, 32),     # the C5 row shape at the default work-group size: 128 columns per work-item (generic kernel)
+    (512, 4096, 5, 16, 64),     # 64 columns per work-item
+    (300, 8192, 3, 6, 128),     # generic kernel, 16 columns per thread, tree levels through LDS
+    (600, 3000, 6, 20, 16),     # K not a multiple of anything, 188 columns per work-item
 ]
 
 
@@ -409,7 +414,10 @@ def test_update_phi_partitioned_pi(orc, hip):
 
 BETA_CASES = [(2048, 64, 500, 64), (2048, 64, 500, 32), (2048, 256, 3000, 128), (1024, 1000, 300, 256),
               (4096, 1024, 1024, 64), (4096, 1024, 1024, 256), (4096, 1024, 1024, 1024),  # wg-beta-test.cc shape
-              (1024, 4096, 1300, 256), (1024, 2048, 300, 128)]  # LDS-streamed kernel with 4 / 2 waves per slot
+              (1024, 4096, 1300, 256), (1024, 2048, 300, 128),  # LDS-streamed kernel with 4 / 2 waves per slot
+              (4096, 1024, 1024, 32),   # wg-beta-test.cc:152-154 at the reference's default beta_wg_size (main.cc:64)
+              (1024, 4096, 700, 32), (1024, 4096, 700, 128),   # C5 rows: 128 / 32 columns per work-item (generic kernel)
+              (1024, 2048, 300, 64), (300, 8192, 200, 256), (600, 3000, 500, 16)]
 
 
 @pytest.mark.parametrize("N,K,n_edges,L", BETA_CASES)
@@ -463,7 +471,8 @@ def test_beta_grads_edge_shards(orc, hip):
 # ----------------------------------------------------------------------------- perplexity
 
 @pytest.mark.parametrize("N,K,L", [(1024, 1024, 64), (1024, 1024, 256), (1024, 1024, 1024), (2048, 96, 32),
-                                   (2048, 1000, 128)])
+                                   (2048, 1000, 128), (1024, 1024, 32),   # the default ppx_wg_size (main.cc:63)
+                                   (512, 4096, 32), (512, 4096, 64), (300, 8192, 128), (600, 3000, 16)])  # generic kernel
 def test_perplexity(orc, hip, N, K, L):
     # wg-perplexity-test.cc:86-108 shape: N=1024, K=1024, ~1024 held-out edges
     pr = Problem(orc, hip, N, K, 8, 16)
@@ -524,9 +533,15 @@ def test_error_behaviour(orc, hip):
     upd.local = 96
     with pytest.raises(hip.AmmsbError, match="invalid argument"):
         upd(pr.nodes, pr.nb, 8)
-    upd.local = 32  # K=2048 needs 64 columns per lane at wg 32: beyond the register-resident forms
+    upd.local = 32  # K=2048 at wg 32 is 64 columns per work-item: the generic kernel (the reference accepts it too)
+    upd(pr.nodes, pr.nb, 8)
+    # beyond every form: more than 32 columns per work-item AND more than 8192 columns
+    import torch
+    big = hip.Context(hip.make_params(64, 16384, E=1024, num_node_sample=4))
+    upd2 = hip.PhiUpdater(big, big.zeros((2 * 16384,), torch.float32), hip.RowPartitionedMatrix(big, 64, 16384),
+                          big.zeros((64,), torch.float32), pr.dset, 8, (42, 43), 32)
     with pytest.raises(hip.AmmsbError, match="out of range"):
-        upd(pr.nodes, pr.nb, 8)
+        upd2(pr.nodes, pr.nb, 8)
     lib = pr.ctx.lib
     assert lib.ammsb_update_phi(None, None, None, None, None, None, None, 1, 1, None, 64, 0, 0, 1, None, None) == -1
     assert lib.ammsb_strerror(-2) == b"HIP runtime error"
