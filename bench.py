@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="nodes/edges in the CPU-baseline sample")
     ap.add_argument("--ppx-calls", type=int, default=5)
+    ap.add_argument("--extras", type=int, default=1,
+                    help="one GPU: also time the workload at the reference's default work-group sizes (32) and, for C3, "
+                         "short C1 and C2 runs (small_configs)")
     return ap.parse_args()
 
 
@@ -258,6 +261,203 @@ def spawn_ranks_if_needed(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def phi_bytes_per_node(K, n):
+    """algorithmic bytes of update_phi per mini-batch node."""
+    return 4 * K * (n + 2) + 68 * n + 8
+
+
+def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_calls):
+    """ppx latency, then `warmup` untimed and EXACTLY `steps` timed iterations of `lrn` (barrier + synchronize on both
+    sides, max over ranks).  Returns the numbers of one bench record."""
+    K, n = cfg.K, cfg.num_node_sample
+
+    def sync():
+        lrn.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- perplexity latency (mean of ppx_calls, after one untimed call)
+    ppx, ppx_ms = None, None
+    if ppx_calls > 0:
+        lrn.HeldoutPerplexity()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(ppx_calls):
+            ppx = lrn.HeldoutPerplexity()
+        sync()
+        ppx_ms = (time.perf_counter() - t0) * 1e3 / ppx_calls
+
+    lrn.Run(warmup)
+    sync()
+    phi = lrn.phiUpdater
+    # Device time of the dominant kernel (update_phi) inside the timed region, per launch.  Eager loop: HIP events
+    # on the launch stream around each launch.  Descriptor loop: device wall-clock stamps written by the first block
+    # of every kernel of the main chain (AMMSB_LOOP_TIMESTAMPS).
+    ev = []
+    orig = phi.update_phi
+
+    def timed_update_phi(nodes, neighbors, nn, lo=0, hi=0xFFFFFFFF):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream())
+        orig(nodes, neighbors, nn, lo, hi)
+        b.record(torch.cuda.current_stream())
+        ev.append((a, b, nn, max(0, min(hi, min(nn, 65535)) - lo)))
+
+    if lrn.loop is None:
+        phi.update_phi = timed_update_phi
+    lrn.step_log = []  # (n_edges, n_nodes) of every step of the timed region (both loops append)
+    first_step = phi.count_calls + 1
+    edges_before = lrn.edges_done
+    sync()
+    prof = None
+    if os.environ.get("AMMSB_BENCH_PROFILE"):  # development aid: cProfile of the enqueue side of the timed region
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    t0 = time.perf_counter()
+    lrn.Run(steps)
+    t_enq = time.perf_counter() - t0  # host side done enqueueing (the device may still be running)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(14)
+    sync()
+    dt = time.perf_counter() - t0
+    phi.update_phi = orig
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    edges_done = lrn.edges_done - edges_before  # identical on every rank: the whole job's mini-batch edges
+    step_log = []
+    for rec in lrn.step_log:
+        if isinstance(rec, np.ndarray):  # descriptor loop: n_edges of a whole call, n_nodes = n_edges + 1
+            step_log.extend(zip(rec.tolist(), (rec + 1).tolist()))
+        else:
+            step_log.append(rec)
+    lrn.step_log = None
+    names = lrn.ctx.kernel_names()  # what the library dispatched to, spelled as rocprofv3 spells it
+
+    # per-launch records of update_phi: (seconds, nodes in the mini-batch, nodes this rank's launch processed)
+    step_classes, value_per_class, kernels = None, None, None
+    if lrn.loop is not None:
+        kept = min(steps, 8192)
+        st = lrn.loop.step_stamps(first_step + steps - kept, kept)  # [kept, 8] ns
+        log = step_log[-kept:]
+        launches = [((st[i, 1] - st[i, 0]) * 1e-9, log[i][1], min(log[i][1], 65535)) for i in range(kept)]
+        # a step's device time = from its update_phi start to the next step's (the sampling chain of the mini-batch two
+        # steps ahead runs beside it); the last step of the window has no successor and is left out
+        dur = (st[1:, 0] - st[:-1, 0]) * 1e-6
+        non = np.array([log[i][0] == m for i in range(kept - 1)], dtype=bool)
+        step_classes = {
+            "nonlink": {"steps": int(non.sum()), "ms_per_step": float(dur[non].mean()) if non.any() else None,
+                        "edges_per_step": m},
+            "link": {"steps": int((~non).sum()), "ms_per_step": float(dur[~non].mean()) if (~non).any() else None,
+                     "edges_per_step": float(np.mean([log[i][0] for i in range(kept - 1) if not non[i]])) if (~non).any() else None},
+            "source": "device wall-clock stamps at the start of consecutive steps' update_phi",
+        }
+        sn, sl = step_classes["nonlink"], step_classes["link"]
+        if sn["ms_per_step"] and sl["ms_per_step"]:
+            # the Node strategy flips a fair coin per step (sample.cc:297): one non-link + one link step is the
+            # expected pair, whatever the window's flips were
+            value_per_class = {
+                "value": (sn["edges_per_step"] + sl["edges_per_step"]) / ((sn["ms_per_step"] + sl["ms_per_step"]) * 1e-3),
+                "unit": "edges/s",
+                "how": "(m + mean link-batch edges) / (non-link step + link step device time): independent of how many "
+                       "of the window's coin flips came up non-link"}
+        # per-kernel device time of the NON-LINK steps (stamp k+1 - stamp k: the kernel plus one boundary) against the
+        # algorithmic bytes of SURVEY 8(d)
+        nl = np.array([log[i][0] == m for i in range(kept)], dtype=bool)
+        ok = nl & (st[:, 0] > 0) & (st[:, 5] >= st[:, 4]) & (st[:, 4] >= st[:, 3]) & (st[:, 3] >= st[:, 2]) & \
+            (st[:, 2] >= st[:, 1]) & (st[:, 1] >= st[:, 0])
+        if ok.any():
+            d = lambda a, b: float((st[ok, b] - st[ok, a]).mean()) * 1e-9  # noqa: E731  (seconds)
+            fused = names["beta_grads"].endswith("true>")  # update_pi folded into the gradient kernel (<..., FUSE = true>)
+            nodes = m + 1
+            b_phi = phi_bytes_per_node(K, n) * nodes
+            b_pi = (8 * K + 8) * nodes
+            b_grads = (4 * K + 72) * m + 4 * K  # the shared end point's row once (node-stratified mini-batch)
+
+            def rec(name, secs, nbytes):
+                return {"kernel": name, "avg_ms": round(secs * 1e3, 5),
+                        "algorithmic_bytes": int(nbytes) if nbytes else None,
+                        "achieved_GBps": round(nbytes / secs / 1e9, 1) if nbytes and secs > 0 else None,
+                        "frac": round(nbytes / secs / 1e9 / 8000.0, 4) if nbytes and secs > 0 else None}
+            kernels = {"update_phi": rec(names["update_phi"], d(0, 1), b_phi)}
+            if fused:
+                kernels["update_pi+beta_grads"] = rec(names["beta_grads"], d(1, 3), b_pi + b_grads)
+            else:
+                kernels["update_pi"] = rec(names["update_pi"], d(1, 2), b_pi)
+                kernels["beta_grads"] = rec(names["beta_grads"], d(2, 3), b_grads)
+            kernels["sum_grads+update_theta"] = rec("sum_update_theta_kernel", d(3, 4), None)
+            kernels["wait_for_sampler"] = {"avg_ms": round(d(4, 5) * 1e3, 5),
+                                           "what": "the main chain's last kernel polling for the next mini-batch"}
+            kernels["source"] = ("device stamps of the %d non-link steps of the timed window; each duration includes one "
+                                 "kernel boundary" % int(ok.sum()))
+    else:
+        launches = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev]
+    big = [(t, nn, g) for t, nn, g in launches if nn > m // 2]
+    roofline = None
+    if big:
+        per_node = phi_bytes_per_node(K, n)
+        nodes_per_launch = float(np.mean([g if nn <= 65535 else nn * (g / 65535.0) for _, nn, g in big]))
+        avg_s = float(np.mean([t for t, _, _ in big]))
+        achieved = per_node * nodes_per_launch / avg_s / 1e9
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "phi_traffic.json")
+        if workload == "C3" and world == 1 and cfg.phi_wg_size == 64 and os.path.exists(tpath):  # the PMC passes were taken on this case
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/phi_traffic.json (stored rocprofv3 --pmc passes of this workload, not measured in this run)"
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": names["update_phi"], "achieved": round(achieved, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "traffic_source": traffic_source,
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": len(big),
+                    "bytes_per_launch": int(per_node * nodes_per_launch),
+                    "timer": "device wall-clock stamps written by the kernels (descriptor loop)" if lrn.loop is not None
+                             else "HIP events on the launch stream"}
+        if step_classes and step_classes["nonlink"]["ms_per_step"]:
+            # step-level: algorithmic bytes of ALL kernels of a non-link iteration / its device time (SURVEY 8d)
+            step_bytes = (m + 1) * (4 * K * (n + 4) + 68 * n + 8) + m * (8 * K + 72) + 24 * K
+            st_s = step_classes["nonlink"]["ms_per_step"] * 1e-3
+            roofline["step"] = {"bytes_per_nonlink_step": int(step_bytes), "achieved": round(step_bytes / st_s / 1e9, 1),
+                                "frac": round(step_bytes / st_s / 1e9 / 8000.0, 4)}
+            pi_bytes = 4.0 * cfg.N * K
+            if pi_bytes <= 256e6:
+                roofline["step"]["note"] = ("pi is %.0f MB: it fits the 256 MB Infinity Cache, so this configuration's "
+                                            "ceiling is the cache's bandwidth, not HBM's 8 TB/s (the fraction is still "
+                                            "quoted against 8 TB/s)" % (pi_bytes / 1e6))
+        if kernels:
+            roofline["kernels"] = kernels
+            if ppx_ms and cfg.ppx_wg_size:
+                H = int(lrn.heldoutPerplexity.edges.numel()) if hasattr(lrn.heldoutPerplexity, "edges") else None
+                if H:
+                    b_ppx = (8 * K + 88) * H
+                    roofline["kernels"]["perplexity"] = {
+                        "kernel": names["perplexity"], "avg_ms": round(ppx_ms, 4), "algorithmic_bytes": int(b_ppx),
+                        "achieved_GBps": round(b_ppx / (ppx_ms * 1e-3) / 1e9, 1),
+                        "frac": round(b_ppx / (ppx_ms * 1e-3) / 1e9 / 8000.0, 4),
+                        "note": "whole HeldoutPerplexity() call (kernel + reduction + the 32-byte read-back), host-timed"}
+    return {"value": edges_done / dt, "ms_per_step": dt * 1e3 / steps, "dt": dt, "edges_done": int(edges_done),
+            "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "step_classes": step_classes,
+            "value_per_class": value_per_class, "roofline": roofline, "ppx_ms": ppx_ms, "ppx": ppx,
+            "kernel_names": names}
+
+
+def sub_record(r, cfg, steps, warmup, loop):
+    """The part of a measure() result that goes into reference_default_wg / small_configs."""
+    rf = r["roofline"] or {}
+    return {"value": r["value"], "unit": "edges/s", "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warmup,
+            "value_per_class": r["value_per_class"], "step_classes": r["step_classes"],
+            "phi_wg": cfg.phi_wg_size, "beta_wg": cfg.beta_wg_size, "ppx_wg": cfg.ppx_wg_size,
+            "kernels_dispatched": r["kernel_names"],
+            "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "step", "kernels")},
+            "ppx_eval_ms": r["ppx_ms"], "loop": loop, "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"]}
+
+
 def main():
     args = parse()
     spawn_ranks_if_needed(args, sys.argv[1:])
@@ -303,141 +503,21 @@ def main():
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.01, rand_seed=1)
     note("training / held-out sets built")
     use_graph = args.loop == "graph" or (args.loop == "auto" and world == 1 and not args.host_sampling)
-    cfg = Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, strategy="Node",
-                                   phi_wg_size=pick_wg(K, args.phi_wg, 16),   # K=1024 -> 64: the LDS-streamed kernel
-                                   beta_wg_size=pick_wg(K, args.beta_wg, 16),  # K=1024 -> 64: the LDS-streamed kernel
-                                   ppx_wg_size=pick_wg(K, args.ppx_wg, 16),   # K=1024 -> 64
-                                   device_sampling=not args.host_sampling,
-                                   graph_launch=use_graph, graph_timestamps=use_graph, phi_exchange=args.exchange)
+
+    def make_cfg(K_, m_, n_, phi_wg, beta_wg, ppx_wg, graph):
+        return Config.from_cli_defaults(K=K_, mini_batch_size=m_, num_node_sample=n_, strategy="Node",
+                                        phi_wg_size=phi_wg, beta_wg_size=beta_wg, ppx_wg_size=ppx_wg,
+                                        device_sampling=not args.host_sampling,
+                                        graph_launch=graph, graph_timestamps=graph, phi_exchange=args.exchange)
+    cfg = make_cfg(K, m, n, pick_wg(K, args.phi_wg, 16),   # K=1024 -> 64: the LDS-streamed kernel
+                   pick_wg(K, args.beta_wg, 16), pick_wg(K, args.ppx_wg, 16), use_graph)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
-    note("learner ready (%s loop)" % ("device-descriptor" if lrn.loop is not None else "eager"))
+    graphs = lrn.loop is not None
+    note("learner ready (%s loop)" % ("device-descriptor" if graphs else "eager"))
 
-    def sync():
-        lrn.drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- perplexity latency (mean of --ppx-calls, after one untimed call)
-    lrn.HeldoutPerplexity()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.ppx_calls):
-        ppx = lrn.HeldoutPerplexity()
-    sync()
-    ppx_ms = (time.perf_counter() - t0) * 1e3 / max(args.ppx_calls, 1)
-
-    # ---- warm-up, then EXACTLY --steps timed iterations
-    lrn.Run(args.warmup)
-    sync()
-    phi = lrn.phiUpdater
-    # Device time of the dominant kernel (update_phi) inside the timed region, per launch.  Eager loop: HIP events
-    # on the launch stream around each launch.  Captured-graph loop: device wall-clock stamps written by two
-    # one-thread kernels around update_phi inside every graph (AMMSB_LOOP_TIMESTAMPS).
-    ev = []
-    orig = phi.update_phi
-
-    def timed_update_phi(nodes, neighbors, nn, lo=0, hi=0xFFFFFFFF):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(torch.cuda.current_stream())
-        orig(nodes, neighbors, nn, lo, hi)
-        b.record(torch.cuda.current_stream())
-        ev.append((a, b, nn, max(0, min(hi, min(nn, 65535)) - lo)))
-
-    if lrn.loop is None:
-        phi.update_phi = timed_update_phi
-    lrn.step_log = []  # (n_edges, n_nodes) of every step of the timed region (both loops append)
-    first_step = phi.count_calls + 1
-    edges_before = lrn.edges_done
-    sync()
-    prof = None
-    if os.environ.get("AMMSB_BENCH_PROFILE"):  # development aid: cProfile of the enqueue side of the timed region
-        import cProfile
-        prof = cProfile.Profile()
-        prof.enable()
-    t0 = time.perf_counter()
-    lrn.Run(args.steps)
-    t_enq = time.perf_counter() - t0  # host side done enqueueing (the device may still be running)
-    if prof is not None:
-        import pstats
-        prof.disable()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(14)
-    sync()
-    dt = time.perf_counter() - t0
-    phi.update_phi = orig
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    edges_done = lrn.edges_done - edges_before  # identical on every rank: the whole job's mini-batch edges
-    step_log = []
-    for rec in lrn.step_log:
-        if isinstance(rec, np.ndarray):  # graph loop: n_edges of a whole call, n_nodes = n_edges + 1
-            step_log.extend(zip(rec.tolist(), (rec + 1).tolist()))
-        else:
-            step_log.append(rec)
-    lrn.step_log = None
-
-    # per-launch records of update_phi: (seconds, nodes in the mini-batch, nodes this rank's launch processed)
-    step_classes = None
-    if lrn.loop is not None:
-        kept = min(args.steps, 8192)
-        b_ns, e_ns = lrn.loop.timestamps(first_step + args.steps - kept, kept)
-        log = step_log[-kept:]
-        launches = [((e_ns[i] - b_ns[i]) * 1e-9, log[i][1], min(log[i][1], 65535)) for i in range(kept)]
-        # a step's device time = from its update_phi start to the next step's (the sampling branch of the next
-        # mini-batch runs inside it); the last step of the window has no successor and is left out
-        dur = (b_ns[1:] - b_ns[:-1]) * 1e-6
-        non = np.array([log[i][0] == m for i in range(kept - 1)], dtype=bool)
-        step_classes = {
-            "nonlink": {"steps": int(non.sum()), "ms_per_step": float(dur[non].mean()) if non.any() else None,
-                        "edges_per_step": m},
-            "link": {"steps": int((~non).sum()), "ms_per_step": float(dur[~non].mean()) if (~non).any() else None,
-                     "edges_per_step": float(np.mean([log[i][0] for i in range(kept - 1) if not non[i]])) if (~non).any() else None},
-            "source": "device wall-clock stamps at the start of consecutive steps' update_phi",
-        }
-    else:
-        launches = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev]
-    big = [(t, nn, g) for t, nn, g in launches if nn > m // 2]
-    roofline = None
-    if big:
-        per_node = 4 * K * (n + 2) + 68 * n + 8  # algorithmic bytes of update_phi per mini-batch node
-        nodes_per_launch = float(np.mean([g if nn <= 65535 else nn * (g / 65535.0) for _, nn, g in big]))
-        avg_s = float(np.mean([t for t, _, _ in big]))
-        achieved = per_node * nodes_per_launch / avg_s / 1e9
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "phi_traffic.json")
-        if args.workload == "C3" and world == 1 and os.path.exists(tpath):  # the PMC passes were taken on this case
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/phi_traffic.json (stored rocprofv3 --pmc passes of this workload, not measured in this run)"
-            except Exception:
-                traffic = None
-        wgp = cfg.phi_wg_size
-        lds_form = K % wgp == 0 and ((wgp == 64 and K // wgp in (4, 8, 16, 32)) or (wgp in (128, 256, 512) and K // wgp == 16))
-        kname = "update_phi_kernel"  # names as in ammsb_phi.hip's dispatch (and in the rocprofv3 kernel trace)
-        if lds_form:
-            kpt = K // wgp
-            if wgp == 64 and kpt == 4 and n % 2 == 0:
-                kname = "update_phi_lds2_kernel<4, 8, %d>" % (4 if n % 4 == 0 else 2)
-            elif wgp == 64 and kpt == 8 and n % 2 == 0:
-                kname = "update_phi_lds2_kernel<8, 4, 2>"
-            else:
-                kname = "update_phi_lds_kernel<%d, %d>" % (kpt, wgp // 64)
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "traffic_source": traffic_source,
-                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches": len(big),
-                    "bytes_per_launch": int(per_node * nodes_per_launch),
-                    "timer": "device wall-clock stamps inside the captured graphs" if lrn.loop is not None
-                             else "HIP events on the launch stream"}
-        if step_classes and step_classes["nonlink"]["ms_per_step"]:
-            # step-level: algorithmic bytes of ALL kernels of a non-link iteration / its device time
-            step_bytes = (m + 1) * (4 * K * (n + 4) + 68 * n + 8) + m * (8 * K + 72) + 24 * K
-            st = step_classes["nonlink"]["ms_per_step"] * 1e-3
-            roofline["step"] = {"bytes_per_nonlink_step": int(step_bytes), "achieved": round(step_bytes / st / 1e9, 1),
-                                "frac": round(step_bytes / st / 1e9 / 8000.0, 4)}
+    r = measure(args, lrn, cfg, m, args.steps, args.warmup, world, dist, torch, args.workload, args.ppx_calls)
+    dt, edges_done, roofline = r["dt"], r["edges_done"], r["roofline"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -446,12 +526,58 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
             cpu = {"value": None, "unit": "mini-batch edges/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     final_ppx = lrn.HeldoutPerplexity()
-    graphs = lrn.loop is not None
+    loop_note = loop_form(graphs)
+    fallback = getattr(lrn, "loop_fallbacks", 0)
+    if fallback:
+        loop_note += "; %d run(s) finished on the stream-event hand-over after a device-side wait gave up" % fallback
+    phi_split = None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
+                                             groups_per_block=lrn.cc, chunks=lrn.nch)
     lrn.close()
+    del lrn
+    torch.cuda.empty_cache()
+
+    # ---- the same workload at the reference's DEFAULT work-group sizes (32 for phi, beta and perplexity, main.cc:61-64)
+    ref_wg = None
+    if rank == 0 and world == 1 and args.extras and (cfg.phi_wg_size, cfg.beta_wg_size, cfg.ppx_wg_size) != (32, 32, 32):
+        try:
+            cfg32 = make_cfg(K, m, n, 32, 32, 32, use_graph)
+            l32 = Learner(cfg32, ds, rank=0, world_size=1)
+            st32 = max(10, min(args.steps, 40))
+            r32 = measure(args, l32, cfg32, m, st32, min(args.warmup, 5), 1, dist, torch, args.workload, 2)
+            ref_wg = sub_record(r32, cfg32, st32, min(args.warmup, 5), loop_form(l32.loop is not None))
+            ref_wg["what"] = ("%s with --phi-wg / --beta-wg / --ppx-wg left at the reference's defaults (32, main.cc:61-64): "
+                              "%d columns per work-item" % (args.workload, (K + 31) // 32))
+            l32.close()
+            del l32
+            torch.cuda.empty_cache()
+            note("reference-default work-groups: %.3e edges/s" % ref_wg["value"])
+        except Exception as e:
+            ref_wg = {"error": repr(e)}
+
+    # ---- the small configurations of BASELINE.json (launch-latency territory), each with its own graph and Learner
+    small = None
+    if rank == 0 and world == 1 and args.extras and args.workload == "C3":
+        small = {}
+        for name, st_small in (("C1", 3000), ("C2", 2000)):
+            try:
+                N2, K2, m2, n2, deg2, kt2 = WORKLOADS[name]
+                e2 = hostlib.generate_graph(N2, kt2, deg2, seed=20260101)
+                ds2 = hostlib.Dataset.robust(N2, e2, heldout_ratio=0.01, rand_seed=1)
+                c2 = make_cfg(K2, m2, n2, pick_wg(K2, 0, 16), pick_wg(K2, 0, 16), pick_wg(K2, 0, 16), use_graph)
+                l2 = Learner(c2, ds2, rank=0, world_size=1)
+                r2 = measure(args, l2, c2, m2, st_small, 200, 1, dist, torch, name, 2)
+                small[name] = sub_record(r2, c2, st_small, 200, loop_form(l2.loop is not None))
+                small[name]["workload"] = "%s: synthetic a-MMSB graph N=%d avg-degree=%d K=%d mini-batch=%d n=%d strategy=Node" \
+                    % (name, N2, deg2, K2, m2, n2)
+                l2.close()
+                del l2, ds2, e2
+                torch.cuda.empty_cache()
+                note("%s: %.4f ms per step" % (name, small[name]["ms_per_step"]))
+            except Exception as e:
+                small[name] = {"error": repr(e)}
+
     cpp = None
     if rank == 0 and world == 1 and args.cpp_dropin and args.workload in ("C1", "C2", "C3"):
-        del lrn
-        torch.cuda.empty_cache()
         try:
             cpp = cpp_dropin(args, hostlib, N, K, m, n, cfg.phi_wg_size, edges, note)
         except Exception as e:
@@ -479,20 +605,22 @@ def main():
                        "sampling": "host(rand_r): the reference's stream" if args.host_sampling else
                                    "device: same distribution as sample.cc, NOT its rand_r stream (same seed does not "
                                    "reproduce a reference trajectory; --host-sampling does)",
-                       "loop": loop_form(graphs),
+                       "loop": loop_note,
                        "host": "python (ctypes -> C ABI); see cpp_dropin for the C++ mcmc::Learner",
                        "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
-                       "phi_split": None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
-                                                                 groups_per_block=lrn.cc, chunks=lrn.nch)},
-            "host_enqueue_ms_per_step": t_enq * 1e3 / args.steps,
-            "step_classes": step_classes,
-            "ppx_eval_ms": ppx_ms,
-            "perplexity": ppx,
+                       "phi_split": phi_split},
+            "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
+            "step_classes": r["step_classes"],
+            "value_per_class": r["value_per_class"],
+            "ppx_eval_ms": r["ppx_ms"],
+            "perplexity": r["ppx"],
             "perplexity_after": final_ppx,
             "mini_batch_edges": int(edges_done),
             "setup_s": round(setup_s, 1),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "reference_default_wg": ref_wg,
+            "small_configs": small,
             "cpp_dropin": cpp,
         }
         print(json.dumps(out))

@@ -293,6 +293,18 @@ int ammsb_loop_check(ammsb_loop* loop, uint32_t* wait_timeouts);
  * began, and at which the kernel after it (update_pi) began -- update_phi's duration plus one kernel boundary: a
  * slight over-estimate, never an under-estimate.  The last 8192 steps are kept.  Synchronises. */
 int ammsb_loop_timestamps(ammsb_loop* loop, uint32_t first_step, uint32_t n_steps, double* begin_ns, double* end_ns);
+/* (AMMSB_LOOP_TIMESTAMPS) every stamp of those steps, out_ns[i * AMMSB_LOOP_STAMP_SLOTS + k] in ns: k = 0 update_phi
+ * starts, 1 update_pi starts (or the gradient kernel that has update_pi folded in), 2 the beta partial-row kernel
+ * starts, 3 the partial-row sum + theta / beta step starts, 4 the step is released (its buffers may be re-sampled),
+ * 5 the next step's mini-batch is available (the chain's last kernel ends).  Consecutive differences are the device
+ * times of the categories PrintStats reports (learner.cc:252-299: PHI, PI, GRADS PAR, GRADS SUM + UPDATE THETA), each
+ * including one kernel boundary; 5 - 4 is the time the main chain waited for the sampling chain. */
+#define AMMSB_LOOP_STAMP_SLOTS 8
+int ammsb_loop_step_stamps(ammsb_loop* loop, uint32_t first_step, uint32_t n_steps, double* out_ns);
+/* Name of the kernel the last ammsb_update_phi / ammsb_update_pi / ammsb_beta_grads / ammsb_perplexity call on this
+ * context dispatched to (which = 0 / 1 / 2 / 3), spelled as the rocprofv3 kernel trace spells it (a substring of the
+ * trace's name column); "" before the first call. */
+const char* ammsb_last_kernel_name(const ammsb_ctx* ctx, int which);
 
 /* ---- wg_* primitives (test entry points; kernels of algorithm/{sum,normalize,sort}.cc) ---- */
 /* WG_SUM_KERNEL_TT, sum.cc:44-52: out[r] = WG_SUM(in + r*len, len) with `wg` lanes (any wg in [1,1024]) */

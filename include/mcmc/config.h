@@ -73,13 +73,17 @@ struct Config {
 
   // new: draw mini-batches on the device instead of with the host samplers above
   bool device_sampling;
-  // new: enqueue-only operators (no Finish() after a launch, no per-launch event timers) and, with
-  // device_sampling, a two-stream loop ordered by events instead of host joins.  Results are identical; the
-  // per-kernel times of PrintStats stay zero.
+  // new: enqueue-only operators (no Finish() after a launch) and, with device_sampling, a two-stream loop ordered by
+  // events instead of host joins.  Results are identical.  The per-kernel times of PrintStats come from event pairs
+  // recorded around every launch and read back at the next synchronisation point (loop_timers below).
   bool async_launch;
   // new: with async_launch + device_sampling, enqueue whole iterations as captured hipGraphs (ammsb_loop,
   // include/ammsb.h): one hipGraphLaunch per iteration instead of a dozen kernel launches.  Results are identical.
   bool graph_launch;
+  // new: per-kernel device times for PrintStats (learner.cc:252-299) in the enqueue-only loops: event pairs around
+  // each launch (async_launch), device time stamps written by the kernels themselves (graph_launch).  On by default;
+  // off removes two event records per launch / a few stores per step.
+  bool loop_timers;
   // new: multi-GPU.  Non-null with world() > 1 => mcmc::Learner shards every iteration over the ranks (one process
   // per GPU, same Config and data on every rank) and exchanges through it (include/mcmc/exchange.h).
   std::shared_ptr<class Exchange> exchange;

@@ -42,6 +42,7 @@ class Learner {
   bool SerializeDeviceSampler(std::ostream* out);
   void RunAsync(uint32_t max_iters, sig_atomic_t* signaled);  // Config::async_launch + device_sampling
   void RunGraph(uint32_t max_iters, sig_atomic_t* signaled);  // Config::graph_launch: iterations as captured graphs
+  void AccountLoopStamps(uint32_t first_step, uint32_t n_steps);  // in-kernel time stamps -> PrintStats categories
   ammsb_mb_choice ChooseDevice();                             // the next mini-batch: (link?, u, deg(u), candidates)
   Float EnqueueDevice(Sample* sample, const ammsb_mb_choice& choice);
   void DrainAsync();

@@ -163,6 +163,30 @@ struct Sample {  // sample.h:51-92
   bool Parse(std::istream* in);
 };
 
+// Device times of enqueue-only launches (Config::async_launch): an event pair is recorded around a launch and read
+// back at the caller's next synchronisation point; nothing waits inside the loop.
+class DeferredTimer {
+ public:
+  DeferredTimer() = default;
+  DeferredTimer(const DeferredTimer&) = delete;
+  DeferredTimer& operator=(const DeferredTimer&) = delete;
+  ~DeferredTimer();
+  void Start(void* stream);                // start event of the launch that follows
+  void Stop(void* stream, uint64_t* acc);  // stop event; *acc += elapsed ns once resolved
+  void Resolve(bool all = true);           // the work is known to have finished (all) / the older half has (else)
+
+ private:
+  struct Rec {
+    void* start;
+    void* stop;
+    uint64_t* acc;
+  };
+  void* Take();
+  std::vector<Rec> pending_;
+  std::vector<void*> free_;
+  void* cur_ = nullptr;
+};
+
 class PhiUpdater {
  public:
   PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta, RowPartitionedMatrix<Float>* pi,
@@ -184,6 +208,13 @@ class PhiUpdater {
   uint32_t& CountCalls() { return count_calls_; }
   uint32_t Local() const { return local_; }
   uint32_t Flags() const { return flags_; }
+  // enqueue-only loops: read back the pending event pairs (the stream has been drained) / add device times measured
+  // elsewhere (the captured-graph loop's in-kernel stamps)
+  void ResolveTimers() { timers_.Resolve(); }
+  void AddTimes(uint64_t phi_ns, uint64_t pi_ns) {
+    t_update_phi_ += phi_ns;
+    t_update_pi_ += pi_ns;
+  }
   bool Serialize(std::ostream* out);  // phi.cc:765-784
   bool Parse(std::istream* in);
 
@@ -198,8 +229,9 @@ class PhiUpdater {
   clcuda::Buffer<Float> phi_vec_;
   random::OpenClRandom rand_;
   uint32_t count_calls_, local_, flags_;
-  bool async_;
+  bool async_, timed_;
   uint64_t t_update_phi_, t_update_pi_;
+  DeferredTimer timers_;
 };
 
 class BetaUpdater {
@@ -226,6 +258,11 @@ class BetaUpdater {
   uint64_t GradsSumTime() const { return 0; }
   uint64_t UpdateThetaTime() const { return t_update_theta_; }
   uint64_t NormalizeTime() const { return 0; }
+  void ResolveTimers() { timers_.Resolve(); }
+  void AddTimes(uint64_t grads_ns, uint64_t update_theta_ns) {
+    t_grads_ += grads_ns;
+    t_update_theta_ += update_theta_ns;
+  }
   bool Serialize(std::ostream* out);  // beta.cc:386-413
   bool Parse(std::istream* in);
 
@@ -241,7 +278,8 @@ class BetaUpdater {
   clcuda::Buffer<Float> grads_;
   uint64_t t_grads_ = 0, t_update_theta_ = 0;
   clcuda::Buffer<Float> theta_sum_;
-  bool async_ = false;
+  bool async_ = false, timed_ = false;
+  DeferredTimer timers_;
 };
 
 class PerplexityCalculator {

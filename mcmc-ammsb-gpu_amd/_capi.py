@@ -65,6 +65,7 @@ SIGNATURES = {
     "ammsb_version": [],
     "ammsb_strerror": [C.c_int],
     "ammsb_last_error": [_vp],
+    "ammsb_last_kernel_name": [_vp, C.c_int],
     "ammsb_params_quantize": [_P(Params)],
     "ammsb_eps_t": [_P(Params), _u32],
     "ammsb_ctx_create": [C.c_int, _P(Params), _P(_vp)],
@@ -97,6 +98,7 @@ SIGNATURES = {
     "ammsb_loop_run": [_vp, _P(MbChoice), _P(MbChoice), _u32, _u32, _u32, _vp],
     "ammsb_loop_check": [_vp, _P(_u32)],
     "ammsb_loop_timestamps": [_vp, _u32, _u32, _P(C.c_double), _P(C.c_double)],
+    "ammsb_loop_step_stamps": [_vp, _u32, _u32, _P(C.c_double)],
     "ammsb_wg_sum_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "ammsb_wg_sum_u32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "ammsb_wg_normalize_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],
@@ -107,7 +109,8 @@ SIGNATURES = {
     "ammsb_randn_fill": [_vp, _vp, _u32, _u32, _vp, _vp],
     "ammsb_rpm_fetch": [_vp, _P(Rpm), _u64, _u64, _vp, _vp],
 }
-_OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_eps_t": C.c_float,
+_OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_last_kernel_name": C.c_char_p,
+              "ammsb_eps_t": C.c_float,
               "ammsb_minibatch_candidates": C.c_uint32, "ammsb_minibatch_candidates_for": C.c_uint32,
               "ammsb_minibatch_workspace_bytes": C.c_uint64, "ammsb_set_num_bins": C.c_uint64}
 

@@ -35,7 +35,15 @@ struct BetaArgs {
   float epsilon;
   const ammsb_step_desc* desc;  // non-null (captured graph): edges [0, desc->n_edges), P = min(n_edges, P)
   ammsb_pi_fusion fuse;         // update_pi folded in (LDS kernels at wg 64, with a descriptor): see ammsb_step.h
+  unsigned long long* stamps;   // optional (with desc): block 0 notes the device time at which it starts
 };
+
+// block 0 notes when the gradient kernel starts; with update_pi folded in that is also when "update_pi" starts
+template <bool FUSE>
+__device__ __forceinline__ void beta_stamp(const BetaArgs& a) {
+  if constexpr (FUSE) note_stamp(a.stamps, a.desc, AMMSB_STAMP_PI);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_GRADS);
+}
 
 struct BetaStep {
   uint32_t edge_begin, edge_end, P;
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   __shared__ float aux[Grp::AUX];
   const int l = Grp::lane();
   const BetaStep st = beta_step(a);
-  if constexpr (FUSE) note_stamp(a.fuse.stamps, a.desc, 1);
+  beta_stamp<FUSE>(a);
   const uint32_t gs = blockIdx.x * Grp::PER_BLOCK + Grp::slot();  // partial-row slot
   const bool live = gs < st.P;
   const uint32_t K = a.K;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   char* wave_smem = smem + wv * (D * KW * sizeof(float));
   float* ring = reinterpret_cast<float*>(wave_smem);
   const BetaStep st = beta_step(a);
-  if constexpr (FUSE) note_stamp(a.fuse.stamps, a.desc, 1);
+  beta_stamp<FUSE>(a);
   const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks (at least P with a descriptor)
   if (gs >= st.P) return;          // block-uniform
   const float EPS = a.epsilon;
@@ -536,6 +544,9 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 template <int KPT, int W>
 int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   const size_t lds = (size_t)W * 4 * sizeof(float) * 64 * KPT;
+  static const std::string name = ammsb_kname("beta_grads_lds_kernel<%d, %d, false>", KPT, W);
+  static const std::string name_fused = ammsb_kname("beta_grads_lds_kernel<%d, %d, true>", KPT, W);
+  ctx->kernel_name[AMMSB_KN_GRADS] = (a.fuse.phi_vec ? name_fused : name).c_str();
   if constexpr (W == 1) {
     if (a.fuse.phi_vec) {
       beta_grads_lds_kernel<KPT, 1, true><<<a.P, 64, lds, s>>>(a);
@@ -639,8 +650,9 @@ __device__ __forceinline__ void theta_step(uint32_t k, float g0, float g1, float
 }
 
 // captured graph: hand the next two descriptors of the ring to the graph that runs next, advance the cursor
-__device__ __forceinline__ void step_advance(const ammsb_step_advance& adv) {
+__device__ __forceinline__ void step_advance(const ammsb_step_advance& adv, const ammsb_step_desc* desc) {
   if (!adv.ring) return;
+  unsigned long long* stamp = adv.stamps ? adv.stamps + AMMSB_STAMP_SLOTS * (desc->step % AMMSB_STAMP_CAP) : nullptr;
   const uint32_t c = *adv.cursor;
   *adv.cur_out = adv.ring[c + 1];
   *adv.nxt_out = adv.ring[c + adv.nxt_offset];
@@ -650,6 +662,7 @@ __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv) {
     __threadfence();
     const uint32_t done = *adv.main_seq + 1u;
     __hip_atomic_store(adv.main_seq, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp) stamp[AMMSB_STAMP_RELEASED] = wall_clock64();
     if (adv.avail) {  // hold this kernel (one lane of one block) until the next step's mini-batch has been sampled
       const unsigned long long t0 = wall_clock64();
       while ((int)(__hip_atomic_load(adv.avail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - done) < 1) {
@@ -660,6 +673,10 @@ __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv) {
         __builtin_amdgcn_s_sleep(8);
       }
     }
+  }
+  if (stamp) {
+    if (!adv.main_seq) stamp[AMMSB_STAMP_RELEASED] = wall_clock64();
+    stamp[AMMSB_STAMP_NEXT] = wall_clock64();
   }
 }
 
@@ -674,7 +691,8 @@ __global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* b
   if (desc) {  // captured graph: this step's scalars
     eps_t = desc->eps_t;
     scale = desc->scale;
-    if (k == 0) step_advance(adv);
+    note_stamp(adv.stamps, desc, AMMSB_STAMP_THETA);
+    if (k == 0) step_advance(adv, desc);
   }
   if (k >= K) return;
   theta_step(k, grads[2 * k], grads[2 * k + 1], theta, beta, seeds, eps_t, scale, eta0, eta1, noise_on, &zig);
@@ -691,6 +709,7 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
   __shared__ float4 red[128][2];
   __shared__ ZigTables zig;
   zig_load(&zig);
+  note_stamp(adv.stamps, desc, AMMSB_STAMP_THETA);
   P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)
   const uint32_t h = threadIdx.x & 1, r = threadIdx.x >> 1;
   const uint32_t c = blockIdx.x * 8 + 4 * h;
@@ -719,7 +738,7 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
   if (r == 0) *reinterpret_cast<float4*>(grads_out + c) = red[0][h];
   // the hand-over (three dependent round trips, then the poll for the next mini-batch) runs in the block's SECOND wave,
   // beside the theta step of the first: neither waits for the other
-  if (blockIdx.x == 0 && threadIdx.x == 64) step_advance(adv);
+  if (blockIdx.x == 0 && threadIdx.x == 64) step_advance(adv, desc);
   if (threadIdx.x < 4) {
     const uint32_t k = blockIdx.x * 4 + threadIdx.x;  // columns 2k, 2k+1 = words (t & 1) * 2, +1 of red[0][t >> 1]
     const float4 g = red[0][threadIdx.x >> 1];
@@ -761,6 +780,7 @@ __global__ __launch_bounds__(512) void beta_grads_gen_kernel(const BetaArgs a, u
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_res + 4);
   uint32_t* s_link = reinterpret_cast<uint32_t*>(s_key + 64);
   const BetaStep st = beta_step(a);
+  beta_stamp<false>(a);
   const uint32_t gs = blockIdx.x;  // partial-row slot
   if (gs >= st.P) return;          // block-uniform
   const float EPS = a.epsilon;
@@ -895,6 +915,7 @@ int launch_grads_gen(ammsb_ctx* ctx, const BetaArgs& a, uint32_t wg, hipStream_t
   const uint32_t T = gen_threads(a.K, wg);
   if (!T) return AMMSB_ERANGE;
   const size_t lds = sizeof(float) * (2 * (size_t)a.K + 2 * wg + 4) + 64 * (sizeof(unsigned long long) + sizeof(uint32_t));
+  ctx->kernel_name[AMMSB_KN_GRADS] = gen_cpt(a.K) == 8 ? "beta_grads_gen_kernel<8>" : "beta_grads_gen_kernel<16>";
   if (gen_cpt(a.K) == 8) beta_grads_gen_kernel<8><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
   else beta_grads_gen_kernel<16><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
   AMMSB_LAUNCH_CHECK(ctx);
@@ -905,6 +926,9 @@ template <int L, int KPT>
 int launch_grads(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   using Grp = Group<L>;
   const uint32_t blocks = (a.P + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  static const std::string name = ammsb_kname("beta_grads_kernel<%d, %d, false>", L, KPT);
+  static const std::string name_fused = ammsb_kname("beta_grads_kernel<%d, %d, true>", L, KPT);
+  ctx->kernel_name[AMMSB_KN_GRADS] = (a.fuse.phi_vec ? name_fused : name).c_str();
   if constexpr ((L == 32 || L == 64) && KPT <= 2) {  // the short-row shapes that take the fusion (beta_fuse_shape)
     if (a.fuse.phi_vec) {
       beta_grads_kernel<L, KPT, true><<<blocks, Grp::BLOCK, 0, s>>>(a);
@@ -975,7 +999,7 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
                              const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
                              uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out,
                              const ammsb_step_desc* desc, bool sum_rows, uint32_t* slots_out, void* stream,
-                             const ammsb_pi_fusion* fuse = nullptr) {
+                             const ammsb_pi_fusion* fuse = nullptr, unsigned long long* stamps = nullptr) {
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && pi && training_set && edges && grads_out, "null argument");
   AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
                   "bad pi descriptor");
@@ -1015,6 +1039,7 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.K = K;
   a.epsilon = ctx->params.epsilon;
   a.desc = desc;
+  a.stamps = desc ? stamps : nullptr;
   a.fuse = ammsb_pi_fusion{nullptr, nullptr, nullptr, nullptr};
   if (fuse && fuse->phi_vec) {
     AMMSB_CHECK_ARG(ctx, desc && fuse->phi_sum && fuse->nodes && beta_fuse_shape(ctx, wg),
@@ -1090,14 +1115,14 @@ int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, co
 int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
                       const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg, float* grads_out, ammsb_seed* seeds,
                       uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv,
-                      const ammsb_pi_fusion* fuse, void* stream) {
+                      const ammsb_pi_fusion* fuse, unsigned long long* stamps, void* stream) {
   AMMSB_CHECK_ARG(ctx, ctx && desc && adv && seeds && n_edges_cap > 0, "null argument / empty capacity");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
   const bool fused = (2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0;
   uint32_t slots = 0;
   int rc = beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges_cap, 0, n_edges_cap, wg, grads_out, desc,
-                             !fused, &slots, stream, fuse);
+                             !fused, &slots, stream, fuse, stamps);
   if (rc != AMMSB_OK) return rc;
   if (!fused) return ammsb_update_theta_d(ctx, theta, beta, grads_out, seeds, flags, desc, adv, stream);
   sum_update_theta_kernel<<<2 * K / 8, 256, 0, as_stream(stream)>>>(ctx->grad_partials, slots, 2 * K, grads_out, theta, beta,
@@ -1137,7 +1162,7 @@ extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, con
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
-  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull};
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull, nullptr};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K,
                                                                      ammsb_eps_t(&p, step_count), scale, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u,
@@ -1151,7 +1176,7 @@ int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float*
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && grads && seeds && desc, "null argument");
   const ammsb_params& p = ctx->params;
   const uint32_t K = (uint32_t)p.K;
-  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull};
+  const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull, nullptr};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K, 0.0f, 0.0f, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc,
                                                                      adv ? *adv : none);

@@ -28,6 +28,11 @@ extern "C" const char* ammsb_strerror(int code) {
 
 extern "C" const char* ammsb_last_error(const ammsb_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
+extern "C" const char* ammsb_last_kernel_name(const ammsb_ctx* ctx, int which) {
+  if (!ctx || which < 0 || which > 3 || !ctx->kernel_name[which]) return "";
+  return ctx->kernel_name[which];
+}
+
 // config.cc:57-64 float_to_string: "%e" (6 digits) + 'f', re-read by the kernel compiler
 static float quantize(float v) {
   char buf[64];

@@ -2,8 +2,11 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+
+#include <string>
 
 #include "../../include/ammsb.h"
 
@@ -18,8 +21,23 @@ struct ammsb_ctx {
   double* ppx_partials;      // [max_ppx_blocks, 2]
   unsigned long long* ppx_cnt_partials;  // [max_ppx_blocks, 2]
   uint32_t max_ppx_blocks;
+  // name of the kernel the last update_phi / update_pi / beta gradient / perplexity call dispatched to, as the
+  // rocprofv3 kernel trace spells it (ammsb_last_kernel_name)
+  const char* kernel_name[4];
   char err[256];
 };
+
+enum { AMMSB_KN_PHI = 0, AMMSB_KN_PI = 1, AMMSB_KN_GRADS = 2, AMMSB_KN_PPX = 3 };
+
+// "kernel<template arguments>" as the demangler prints it; one static string per launcher instantiation
+static inline std::string ammsb_kname(const char* fmt, ...) {
+  char buf[128];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return std::string(buf);
+}
 
 #define AMMSB_CHECK_ARG(ctx, cond, msg)                                   \
   do {                                                                    \

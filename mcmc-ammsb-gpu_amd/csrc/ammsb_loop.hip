@@ -113,7 +113,7 @@ struct ammsb_loop {
   uint32_t* d_hs;                // hand-shake counters (HS_*)
   bool use_events;               // AMMSB_LOOP_HANDSHAKE=event: also order the chains with stream events
   unsigned long long wait_ticks; // a wait gives up after this many wall-clock ticks
-  unsigned long long* d_stamps;  // [STAMP_CAP][2] or null
+  unsigned long long* d_stamps;  // [STAMP_CAP][AMMSB_STAMP_SLOTS] or null
   Stage stage[2];
   int next_stage;
   hipGraphExec_t exec_main[2][NBUF][2];  // [this step link][physical buffer read][descriptor parity]
@@ -201,9 +201,9 @@ int record_main(ammsb_loop* lp, int cl, int b, int dp, hipStream_t st) {
   const bool hs = !lp->use_events;
   const ammsb_step_advance adv = {lp->d_ring, lp->d_cursor, lp->d_cur[1 - dp], lp->d_nxt[b], 3u,
                                   hs ? lp->d_hs + HS_MAIN : nullptr, hs ? lp->d_hs + HS_AVAIL : nullptr,
-                                  hs ? lp->d_hs + HS_TIMEOUTS : nullptr, lp->wait_ticks};
+                                  hs ? lp->d_hs + HS_TIMEOUTS : nullptr, lp->wait_ticks, lp->d_stamps};
   LOOP_RC(ammsb_beta_step_d(ctx, c.theta, c.beta, &lp->pi, &lp->training, in.edges, cap_edges, c.beta_wg, c.grads,
-                            c.beta_seeds, c.beta_flags, cur, &adv, fuse_pi ? &fuse : nullptr, st));
+                            c.beta_seeds, c.beta_flags, cur, &adv, fuse_pi ? &fuse : nullptr, lp->d_stamps, st));
   return AMMSB_OK;
 }
 
@@ -402,8 +402,8 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     st.used = false;
   }
   if (c.flags & AMMSB_LOOP_TIMESTAMPS) {
-    CREATE_HIP(hipMalloc(&lp->d_stamps, sizeof(unsigned long long) * 2 * STAMP_CAP));
-    CREATE_HIP(hipMemset(lp->d_stamps, 0, sizeof(unsigned long long) * 2 * STAMP_CAP));
+    CREATE_HIP(hipMalloc(&lp->d_stamps, sizeof(unsigned long long) * AMMSB_STAMP_SLOTS * STAMP_CAP));
+    CREATE_HIP(hipMemset(lp->d_stamps, 0, sizeof(unsigned long long) * AMMSB_STAMP_SLOTS * STAMP_CAP));
     CREATE_HIP(hipDeviceGetAttribute(&lp->wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
   }
 #undef CREATE_HIP
@@ -600,27 +600,44 @@ extern "C" int ammsb_loop_check(ammsb_loop* lp, uint32_t* wait_timeouts) {
   return AMMSB_OK;
 }
 
-extern "C" int ammsb_loop_timestamps(ammsb_loop* lp, uint32_t first_step, uint32_t n_steps, double* begin_ns,
-                                     double* end_ns) {
+// all stamps of steps first_step .. first_step + n_steps - 1 in ns: out[i][AMMSB_STAMP_*] (AMMSB_STAMP_SLOTS doubles per step)
+extern "C" int ammsb_loop_step_stamps(ammsb_loop* lp, uint32_t first_step, uint32_t n_steps, double* out_ns) {
   if (!lp) return AMMSB_EINVAL;
   ammsb_ctx* ctx = lp->ctx;
   AMMSB_CHECK_ARG(ctx, lp->d_stamps, "the loop was created without AMMSB_LOOP_TIMESTAMPS");
-  AMMSB_CHECK_ARG(ctx, begin_ns && end_ns && n_steps <= STAMP_CAP, "bad argument (at most 8192 steps are kept)");
+  AMMSB_CHECK_ARG(ctx, out_ns && n_steps <= STAMP_CAP, "bad argument (at most 8192 steps are kept)");
   LOOP_HIP(lp, hipStreamSynchronize(lp->main));
-  unsigned long long* host = new (std::nothrow) unsigned long long[2 * STAMP_CAP];
+  const size_t words = (size_t)AMMSB_STAMP_SLOTS * STAMP_CAP;
+  unsigned long long* host = new (std::nothrow) unsigned long long[words];
   if (!host) return AMMSB_ENOMEM;
-  const hipError_t e = hipMemcpy(host, lp->d_stamps, sizeof(unsigned long long) * 2 * STAMP_CAP, hipMemcpyDeviceToHost);
+  const hipError_t e = hipMemcpy(host, lp->d_stamps, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost);
   if (e != hipSuccess) {
     delete[] host;
-    snprintf(ctx->err, sizeof ctx->err, "ammsb_loop_timestamps: hipMemcpy -> %s", hipGetErrorString(e));
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_loop_step_stamps: hipMemcpy -> %s", hipGetErrorString(e));
     return AMMSB_EHIP;
   }
   const double ns_per_tick = 1.0e6 / static_cast<double>(lp->wall_khz > 0 ? lp->wall_khz : 100000);
   for (uint32_t i = 0; i < n_steps; ++i) {
     const uint32_t slot = (first_step + i) % STAMP_CAP;
-    begin_ns[i] = static_cast<double>(host[2 * slot]) * ns_per_tick;
-    end_ns[i] = static_cast<double>(host[2 * slot + 1]) * ns_per_tick;
+    for (uint32_t w = 0; w < AMMSB_STAMP_SLOTS; ++w)
+      out_ns[(size_t)i * AMMSB_STAMP_SLOTS + w] = static_cast<double>(host[(size_t)AMMSB_STAMP_SLOTS * slot + w]) * ns_per_tick;
   }
   delete[] host;
   return AMMSB_OK;
+}
+
+extern "C" int ammsb_loop_timestamps(ammsb_loop* lp, uint32_t first_step, uint32_t n_steps, double* begin_ns,
+                                     double* end_ns) {
+  if (!lp) return AMMSB_EINVAL;
+  ammsb_ctx* ctx = lp->ctx;
+  AMMSB_CHECK_ARG(ctx, begin_ns && end_ns && n_steps <= STAMP_CAP, "bad argument (at most 8192 steps are kept)");
+  double* all = new (std::nothrow) double[(size_t)AMMSB_STAMP_SLOTS * (n_steps ? n_steps : 1)];
+  if (!all) return AMMSB_ENOMEM;
+  const int rc = ammsb_loop_step_stamps(lp, first_step, n_steps, all);
+  for (uint32_t i = 0; rc == AMMSB_OK && i < n_steps; ++i) {
+    begin_ns[i] = all[(size_t)i * AMMSB_STAMP_SLOTS + AMMSB_STAMP_PHI];
+    end_ns[i] = all[(size_t)i * AMMSB_STAMP_SLOTS + AMMSB_STAMP_PI];
+  }
+  delete[] all;
+  return rc;
 }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
   const int slot = Grp::slot();
   uint32_t* s_nb = s_nb_all + slot * a.n;
   const PhiStep st = phi_step(a);
-  note_stamp(a.stamps, a.desc, 0);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
   const uint32_t g = a.group_begin + blockIdx.x * Grp::PER_BLOCK + slot;
   const bool live = g < st.group_end;
   const uint32_t K = a.K, n = a.n;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
   };
 
   const PhiStep st = phi_step(a);
-  note_stamp(a.stamps, a.desc, 0);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
   if constexpr (NB > 1) {  // every wave of the block helps loading the shared tables before any of them may leave
     if (a.noise_on) zig_load(&zig);
     __syncthreads();
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
   float nz[REGN ? KPT : 1];
 
   const PhiStep st = phi_step(a);
-  note_stamp(a.stamps, a.desc, 0);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
   const uint32_t g = a.group_begin + blockIdx.x;
   if (g >= st.group_end) return;  // block-uniform
   const uint32_t n = a.n;
@@ -883,6 +883,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
 template <int KPT, int D, int U>
 int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
+  static const std::string name = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d>", KPT, D, U);
+  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
   update_phi_lds2_kernel<KPT, D, U><<<n_groups, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
@@ -891,6 +893,8 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
 template <int KPT, int W, int D = 2, int NB = 1>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t per_node = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + ((sizeof(uint32_t) * a.n + 15) & ~(size_t)15);
+  static const std::string name = ammsb_kname("update_phi_lds_kernel<%d, %d, %d, %d>", KPT, W, D, NB);
+  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
   update_phi_lds_kernel<KPT, W, D, NB><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_pi_kernel(ammsb_rpm pi
   using Grp = Group<L>;
   __shared__ float aux[Grp::AUX];
   if (desc) n_nodes = desc->n_nodes;  // captured graph: the grid covers the largest mini-batch
-  note_stamp(stamps, desc, 1);
+  note_stamp(stamps, desc, AMMSB_STAMP_PI);
   const int l = Grp::lane();
   const uint64_t i = (uint64_t)blockIdx.x * Grp::PER_BLOCK + Grp::slot();
   const bool on = i < n_nodes;
@@ -939,6 +943,9 @@ int launch_phi(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t 
   constexpr int DEPTH = KPT >= 32 ? 2 : 4;
   const uint32_t blocks = (n_groups + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
   const size_t lds = sizeof(uint32_t) * Grp::PER_BLOCK * a.n;
+  static const std::string name_full = ammsb_kname("update_phi_kernel<%d, %d, %d, true>", L, KPT, DEPTH);
+  static const std::string name_part = ammsb_kname("update_phi_kernel<%d, %d, %d, false>", L, KPT, DEPTH);
+  ctx->kernel_name[AMMSB_KN_PHI] = (a.K == (uint32_t)(L * KPT) ? name_full : name_part).c_str();
   if (a.K == (uint32_t)(L * KPT))
     update_phi_kernel<L, KPT, DEPTH, true><<<blocks, Grp::BLOCK, lds, s>>>(a);
   else
@@ -952,6 +959,8 @@ int launch_pi(ammsb_ctx* ctx, const ammsb_rpm& pi, float* phi_sum, const float* 
               uint32_t n_nodes, uint32_t K, const ammsb_step_desc* desc, unsigned long long* stamps, hipStream_t s) {
   using Grp = Group<L>;
   const uint32_t blocks = (n_nodes + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  static const std::string name = ammsb_kname("update_pi_kernel<%d, %d>", L, KPT);
+  ctx->kernel_name[AMMSB_KN_PI] = name.c_str();
   update_pi_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(pi, phi_sum, phi_vec, nodes, n_nodes, K, desc, stamps);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, ui
   uint32_t* s_nb = reinterpret_cast<uint32_t*>(s_res + 2);
 
   const PhiStep st = phi_step(a);
-  note_stamp(a.stamps, a.desc, 0);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
   const uint32_t g = a.group_begin + blockIdx.x;
   if (g >= st.group_end) return;  // block-uniform
   const float EPS = a.epsilon;
@@ -1118,7 +1127,7 @@ __global__ __launch_bounds__(512) void update_pi_gen_kernel(ammsb_rpm pi, float*
   float* s_aux = s_vals + K;
   float* s_res = s_aux + L;
   if (desc) n_nodes = desc->n_nodes;
-  note_stamp(stamps, desc, 1);
+  note_stamp(stamps, desc, AMMSB_STAMP_PI);
   const uint64_t i = blockIdx.x;
   if (i >= n_nodes) return;  // block-uniform
   const uint32_t T = blockDim.x, t = threadIdx.x;
@@ -1166,6 +1175,7 @@ int launch_phi_gen(ammsb_ctx* ctx, const PhiArgs& a, uint32_t wg, uint32_t n_gro
   const uint32_t T = gen_threads(a.K, wg, 1);
   if (!T) return AMMSB_ERANGE;
   const size_t lds = sizeof(float) * ((size_t)a.K + wg + 2) + sizeof(uint32_t) * a.n;
+  ctx->kernel_name[AMMSB_KN_PHI] = gen_cpt(a.K) == 8 ? "update_phi_gen_kernel<8>" : "update_phi_gen_kernel<16>";
   if (gen_cpt(a.K) == 8) update_phi_gen_kernel<8><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
   else update_phi_gen_kernel<16><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
   AMMSB_LAUNCH_CHECK(ctx);
@@ -1382,6 +1392,7 @@ static int update_pi_common(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum,
       return AMMSB_ERANGE;
     }
     const size_t lds = sizeof(float) * ((size_t)K + wg + 2);
+    ctx->kernel_name[AMMSB_KN_PI] = gen_cpt(K) == 8 ? "update_pi_gen_kernel<8>" : "update_pi_gen_kernel<16>";
     if (gen_cpt(K) == 8)
       update_pi_gen_kernel<8><<<n_nodes, T, lds, s>>>(*pi, phi_sum, phi_vec, nodes, n_nodes, K, wg, ilog2_u32(wg), desc, stamps);
     else

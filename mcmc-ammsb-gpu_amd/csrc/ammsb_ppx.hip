@@ -376,6 +376,7 @@ int launch_ppx_gen(ammsb_ctx* ctx, const PpxArgs& a, uint32_t wg, hipStream_t s)
   const uint32_t T = gen_threads(a.K, wg);
   if (!T) return AMMSB_ERANGE;
   const size_t lds = sizeof(float) * (2 * (size_t)a.K + 2 * wg + 4);
+  ctx->kernel_name[AMMSB_KN_PPX] = gen_cpt(a.K) == 8 ? "ppx_gen_kernel<8>" : "ppx_gen_kernel<16>";
   if (gen_cpt(a.K) == 8) ppx_gen_kernel<8><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
   else ppx_gen_kernel<16><<<a.P, T, lds, s>>>(a, wg, ilog2_u32(wg));
   AMMSB_LAUNCH_CHECK(ctx);
@@ -387,6 +388,8 @@ int launch_ppx_lds(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
   // two-edge ring: 16 KiB per wave, so the 8 slots per CU the launch asks for are resident at once (a three-edge
   // ring at 24 KiB fits 6 and needs a second round: 0.335 vs 0.250 ms at C3; 1536 slots x 3 edges ties at 0.247)
   const size_t lds = (size_t)2 * 2 * sizeof(float) * 64 * KPT;
+  static const std::string name = ammsb_kname("ppx_lds_kernel<%d, 2u>", KPT);
+  ctx->kernel_name[AMMSB_KN_PPX] = name.c_str();
   ppx_lds_kernel<KPT, 2><<<a.P, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
@@ -432,6 +435,8 @@ template <int L, int KPT>
 int launch_ppx(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
   using Grp = Group<L>;
   const uint32_t blocks = (a.P + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
+  static const std::string name = ammsb_kname("ppx_kernel<%d, %d>", L, KPT);
+  ctx->kernel_name[AMMSB_KN_PPX] = name.c_str();
   ppx_kernel<L, KPT><<<blocks, Grp::BLOCK, 0, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;

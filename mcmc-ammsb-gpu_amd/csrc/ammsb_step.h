@@ -11,7 +11,17 @@
 
 #include "../../include/ammsb.h"
 
-#define AMMSB_STAMP_CAP 8192u  // steps whose update_phi time stamps are kept (ring indexed by step number)
+#define AMMSB_STAMP_CAP 8192u  // steps whose time stamps are kept (ring indexed by step number)
+// Stamps of one step (device wall clock, one 8-word record per step): the first block of each kernel of the main chain
+// notes when it starts, the hand-over lane of the last kernel when it has released the step and when its poll for the
+// next mini-batch is satisfied.  Kernel k's duration (plus one kernel boundary) = stamp k + 1 - stamp k.
+#define AMMSB_STAMP_SLOTS 8u
+#define AMMSB_STAMP_PHI 0u       // update_phi starts
+#define AMMSB_STAMP_PI 1u        // update_pi starts (or the gradient kernel that has update_pi folded in)
+#define AMMSB_STAMP_GRADS 2u     // the beta partial-row kernel starts (== AMMSB_STAMP_PI when update_pi is folded in)
+#define AMMSB_STAMP_THETA 3u     // the partial-row sum + theta / beta step starts
+#define AMMSB_STAMP_RELEASED 4u  // the step's main chain is counted as done (the sampler chain may reuse its buffers)
+#define AMMSB_STAMP_NEXT 5u      // the next step's mini-batch is available: the chain's last kernel may end
 
 struct ammsb_step_desc {
   uint32_t n_nodes;  // mini-batch nodes (phi / pi / neighbour sampler)
@@ -39,17 +49,18 @@ struct ammsb_step_advance {
   const uint32_t* avail;
   uint32_t* timeouts;
   unsigned long long max_ticks;
+  unsigned long long* stamps;  // optional: AMMSB_STAMP_RELEASED / AMMSB_STAMP_NEXT of this step
 };
 
 #ifdef __HIPCC__
-// Device wall-clock stamps without extra launches: block 0 of update_phi notes when it starts (slot 0), block 0 of
-// the next kernel on the stream (update_pi, or the gradient kernel that has update_pi fused in) when IT starts
-// (slot 1).  The difference is update_phi's duration plus one kernel boundary: a slight over-estimate, never an
-// under-estimate.
+// Device wall-clock stamps without extra launches: block 0 of every kernel of the main chain notes when it starts
+// (AMMSB_STAMP_*).  The difference of two consecutive stamps is a kernel's duration plus one kernel boundary: a slight
+// over-estimate, never an under-estimate.
 // (not inlined on purpose: inlined at the top of update_phi_lds_kernel<16, 1> it cost the K = 1024 kernel two spilled
 // registers -- 8 bytes of scratch per lane -- for a store one thread of one block makes)
 static __device__ __noinline__ void note_stamp_slow(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
-  if (desc && blockIdx.x == 0 && threadIdx.x == 0) stamps[2 * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
+  if (desc && blockIdx.x == 0 && threadIdx.x == 0)
+    stamps[AMMSB_STAMP_SLOTS * (desc->step % AMMSB_STAMP_CAP) + which] = wall_clock64();
 }
 static __device__ __forceinline__ void note_stamp(unsigned long long* stamps, const ammsb_step_desc* desc, uint32_t which) {
   if (stamps) note_stamp_slow(stamps, desc, which);  // wave-uniform: a call only when time stamps are on
@@ -83,7 +94,7 @@ int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float*
 int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
                       const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg, float* grads_out, ammsb_seed* seeds,
                       uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv,
-                      const ammsb_pi_fusion* fuse, void* stream);
+                      const ammsb_pi_fusion* fuse, unsigned long long* stamps, void* stream);
 int ammsb_sample_neighbors_d(ammsb_ctx* ctx, ammsb_seed* seeds, const uint32_t* nodes, uint32_t n_nodes_cap, uint32_t wg,
                              uint32_t* table, uint32_t* packed, const ammsb_step_desc* desc, void* stream);
 int ammsb_minibatch_link_d(ammsb_ctx* ctx, const uint64_t* csr_offsets, const uint32_t* csr_targets, uint32_t n_cap,

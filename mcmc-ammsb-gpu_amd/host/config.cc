@@ -47,6 +47,7 @@ Config::Config() {  // config.h:69-101
   training_ppx_ratio = 0.01;  // config.h:72
   training_ppx_seed = 1;
   graph_launch = false;
+  loop_timers = true;
   device_sampling_seed = {1234, 5678};
   device_sampling_host_seed = 20260101;
   sample_seed[0] = 1804289383u;

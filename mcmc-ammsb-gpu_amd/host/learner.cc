@@ -199,7 +199,7 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
     lc.max_fan_out = static_cast<uint32_t>(cfg_.trainingGraph->MaxFanOut());
     lc.max_nodes = static_cast<uint32_t>(samples_[0]->dev_nodes.Count());
     lc.max_edges = static_cast<uint32_t>(samples_[0]->dev_edges.Count());
-    lc.flags = 0;
+    lc.flags = cfg_.loop_timers ? AMMSB_LOOP_TIMESTAMPS : 0u;
     queue_.Finish();
     ThrowIfError(ctx_.get(), ammsb_loop_create(ctx_.get(), &lc, &loop_), "ammsb_loop_create");
   }
@@ -534,17 +534,48 @@ void Learner::DrainAsync() {
   if (!cfg_.async_launch) return;
   for (auto& smp : samples_) smp->queue.Finish();
   queue_.Finish();
+  phiUpdater_.ResolveTimers();  // event pairs of the enqueue-only launches (Config::loop_timers)
+  betaUpdater_.ResolveTimers();
+}
+
+// The captured-graph loop's kernels note the device time they start at (include/ammsb.h, ammsb_loop_step_stamps):
+// the differences are the categories of PrintStats.  The sum of the partial rows and the theta / beta step are one
+// kernel here and are counted under UPDATE THETA; the time the main chain waited for the next mini-batch is SAMPLING
+// (the reference's SAMPLING is the host's wait for the sampler thread, learner.cc:225-235).  The last 8192 steps of
+// a longer call stand for all of them.
+void Learner::AccountLoopStamps(uint32_t first_step, uint32_t n_steps) {
+  if (!loop_ || !cfg_.loop_timers || n_steps == 0) return;
+  const uint32_t kept = std::min<uint32_t>(n_steps, 8192);
+  std::vector<double> st(static_cast<size_t>(kept) * AMMSB_LOOP_STAMP_SLOTS);
+  ThrowIfError(ctx_.get(), ammsb_loop_step_stamps(loop_, first_step + (n_steps - kept), kept, st.data()),
+               "ammsb_loop_step_stamps");
+  double phi = 0, pi = 0, grads = 0, theta = 0, wait = 0;
+  for (uint32_t i = 0; i < kept; ++i) {
+    const double* s = &st[static_cast<size_t>(i) * AMMSB_LOOP_STAMP_SLOTS];
+    if (!(s[0] > 0 && s[1] >= s[0] && s[2] >= s[1] && s[3] >= s[2] && s[4] >= s[3] && s[5] >= s[4])) continue;
+    phi += s[1] - s[0];
+    pi += s[2] - s[1];
+    grads += s[3] - s[2];
+    theta += s[4] - s[3];
+    wait += s[5] - s[4];
+  }
+  const double scale = static_cast<double>(n_steps) / kept;
+  phiUpdater_.AddTimes(static_cast<uint64_t>(phi * scale), static_cast<uint64_t>(pi * scale));
+  betaUpdater_.AddTimes(static_cast<uint64_t>(grads * scale), static_cast<uint64_t>(theta * scale));
+  samplingTime_ += static_cast<uint64_t>(wait * scale);
 }
 
 void Learner::Run(uint32_t max_iters, sig_atomic_t* signaled) {
   const auto t1 = high_resolution_clock::now();
   if (cfg_.async_launch) {
+    const uint32_t first_step = phiUpdater_.CountCalls() + 1;
     if (loop_)
       RunGraph(max_iters, signaled);
     else
       RunAsync(max_iters, signaled);
     DrainAsync();  // Run() returns with the work done, like the reference's
     CheckDeviceSampler();
+    if (loop_) AccountLoopStamps(first_step, phiUpdater_.CountCalls() + 1 - first_step);
     time_ += duration_cast<nanoseconds>(high_resolution_clock::now() - t1).count();
     return;
   }

@@ -120,6 +120,7 @@ int main(int argc, char** argv) {
       Opt("device-sampling", 0, &cfg.device_sampling, "0 (new: draw mini-batches on the device)"),
       Opt("async", 0, &cfg.async_launch, "0 (new: enqueue-only loop; needs --device-sampling 1)"),
       Opt("graph", 0, &cfg.graph_launch, "0 (new: iterations as captured hipGraphs; needs --async 1)"),
+      Opt("loop-timers", 0, &cfg.loop_timers, "1 (new: per-kernel device times in PrintStats under --async / --graph)"),
       OptStr("exchange", 0, &exchangeKind),  // (new) rccl | host: one process per GPU, RANK / WORLD_SIZE / MASTER_* from the env
       Opt("device", 0, &deviceId, "-1 (new: HIP device; default LOCAL_RANK with --exchange, else 0)"),
       OptStr("checkpoint-in", 0, &ckptIn),    // (new) Learner::Parse before the first iteration

@@ -222,6 +222,56 @@ struct EventTimer {  // device time of one enqueue, like clcuda::Event::GetElaps
 };
 }  // namespace
 
+// ---------------------------------------------------------------------------- DeferredTimer
+
+DeferredTimer::~DeferredTimer() {
+  for (Rec& r : pending_) {
+    (void)hipEventDestroy(static_cast<hipEvent_t>(r.start));
+    (void)hipEventDestroy(static_cast<hipEvent_t>(r.stop));
+  }
+  for (void* e : free_) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  if (cur_) (void)hipEventDestroy(static_cast<hipEvent_t>(cur_));
+}
+
+void* DeferredTimer::Take() {
+  if (!free_.empty()) {
+    void* e = free_.back();
+    free_.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  clcuda::Check(hipEventCreate(&e), "hipEventCreate");
+  return e;
+}
+
+void DeferredTimer::Start(void* stream) {
+  if (pending_.size() >= 4096) Resolve(false);  // a very long Run(): keep the pool bounded
+  if (!cur_) cur_ = Take();
+  clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(cur_), static_cast<hipStream_t>(stream)), "hipEventRecord");
+}
+
+void DeferredTimer::Stop(void* stream, uint64_t* acc) {
+  void* stop = Take();
+  clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(stop), static_cast<hipStream_t>(stream)), "hipEventRecord");
+  pending_.push_back(Rec{cur_, stop, acc});
+  cur_ = nullptr;
+}
+
+void DeferredTimer::Resolve(bool all) {
+  const size_t n = all ? pending_.size() : pending_.size() / 2;
+  if (n == 0) return;
+  clcuda::Check(hipEventSynchronize(static_cast<hipEvent_t>(pending_[n - 1].stop)), "hipEventSynchronize");
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, static_cast<hipEvent_t>(pending_[i].start), static_cast<hipEvent_t>(pending_[i].stop)) ==
+        hipSuccess)
+      *pending_[i].acc += static_cast<uint64_t>(static_cast<double>(ms) * 1.0e6);
+    free_.push_back(pending_[i].start);
+    free_.push_back(pending_[i].stop);
+  }
+  pending_.erase(pending_.begin(), pending_.begin() + static_cast<std::ptrdiff_t>(n));
+}
+
 PhiUpdater::PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
                        RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Float>& phi, OpenClSet* trainingSet,
                        const std::vector<std::string>&, const std::string&)
@@ -238,6 +288,7 @@ PhiUpdater::PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Fl
       local_(cfg.phi_wg_size),
       flags_(cfg.phi_disable_noise ? AMMSB_NOISE_OFF : 0u),
       async_(cfg.async_launch),
+      timed_(cfg.async_launch && cfg.loop_timers && !cfg.graph_launch),
       t_update_phi_(0),
       t_update_pi_(0) {}
 
@@ -246,15 +297,21 @@ void PhiUpdater::operator()(clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Vertex
   if (n > max_nodes_) throw std::runtime_error("grads too small");     // phi.cc:734-737
   ++count_calls_;
   if (async_) {
+    if (timed_) timers_.Start(queue_.stream());
     ThrowIfError(ctx_.get(),
                  ammsb_update_phi(ctx_.get(), beta_.data(), &pi_->Get(), phi_.data(), &trainingSet_->Get(), nodes.data(),
                                   neighbors.data(), n, count_calls_, rand_.Get(), local_, flags_, 0, 0xFFFFFFFFu,
                                   phi_vec_.data(), queue_.stream()),
                  "ammsb_update_phi");
+    if (timed_) {
+      timers_.Stop(queue_.stream(), &t_update_phi_);
+      timers_.Start(queue_.stream());
+    }
     ThrowIfError(ctx_.get(),
                  ammsb_update_pi(ctx_.get(), &pi_->Get(), phi_.data(), phi_vec_.data(), nodes.data(), n, local_,
                                  queue_.stream()),
                  "ammsb_update_pi");
+    if (timed_) timers_.Stop(queue_.stream(), &t_update_pi_);
     return;
   }
   {
@@ -328,6 +385,7 @@ BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::B
       grads_(queue.GetContext(), 2 * cfg.K),
       theta_sum_(queue.GetContext(), cfg.K) {
   async_ = cfg.async_launch;
+  timed_ = cfg.async_launch && cfg.loop_timers && !cfg.graph_launch;
 }
 
 clcuda::Buffer<Float>& BetaUpdater::GetThetaSum() {
@@ -339,14 +397,20 @@ clcuda::Buffer<Float>& BetaUpdater::GetThetaSum() {
 void BetaUpdater::operator()(clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float scale) {
   ++count_calls_;  // beta.cc:336
   if (async_) {
+    if (timed_) timers_.Start(queue_.stream());
     ThrowIfError(ctx_.get(),
                  ammsb_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), &trainingSet_->Get(), edges->data(),
                                   num_edges, 0, num_edges, local_, grads_.data(), queue_.stream()),
                  "ammsb_beta_grads");
+    if (timed_) {
+      timers_.Stop(queue_.stream(), &t_grads_);
+      timers_.Start(queue_.stream());
+    }
     ThrowIfError(ctx_.get(),
                  ammsb_update_theta(ctx_.get(), theta_.data(), beta_.data(), grads_.data(), count_calls_, scale,
                                     rand_.Get(), 0, queue_.stream()),
                  "ammsb_update_theta");
+    if (timed_) timers_.Stop(queue_.stream(), &t_update_theta_);
     return;
   }
   EventTimer tg(queue_.stream());

@@ -111,6 +111,13 @@ class Context:
     def check(self, rc):
         check(rc, self._ctx)
 
+    KERNELS = ("update_phi", "update_pi", "beta_grads", "perplexity")
+
+    def kernel_names(self):
+        """Names of the kernels the last update_phi / update_pi / gradient / perplexity calls on this context
+        dispatched to, spelled as in a rocprofv3 kernel trace (ammsb_last_kernel_name)."""
+        return {k: self.lib.ammsb_last_kernel_name(self.handle, i).decode() for i, k in enumerate(self.KERNELS)}
+
     def close(self):
         if self._ctx:
             self.lib.ammsb_ctx_destroy(self._ctx)
@@ -680,6 +687,18 @@ class GraphLoop:
         self.ctx.check(self.ctx.lib.ammsb_loop_timestamps(self._h, int(first_step), int(n), b.ctypes.data_as(dp),
                                                           e.ctypes.data_as(dp)))
         return b, e
+
+    STAMP_SLOTS = 8  # AMMSB_LOOP_STAMP_SLOTS
+    STAMP_NAMES = ("update_phi", "update_pi", "beta_grads", "sum_theta", "released", "next_batch")
+
+    def step_stamps(self, first_step, n):
+        """[n, 8] device times in ns of steps first_step .. first_step + n - 1 (include/ammsb.h,
+        ammsb_loop_step_stamps): columns 0..3 = start of update_phi / update_pi / the partial-row kernel / the
+        partial-row sum + theta step, 4 = step released, 5 = next mini-batch available.  Synchronises."""
+        out = np.zeros((int(n), self.STAMP_SLOTS), dtype=np.float64)
+        self.ctx.check(self.ctx.lib.ammsb_loop_step_stamps(self._h, int(first_step), int(n),
+                                                           out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def close(self):
         if self._h:

@@ -131,7 +131,7 @@ def test_cli_reference_default_work_groups_at_k1024(exe, tmp_path, loop):
     and the neighbour sampler (main.cc:61-64), i.e. 32 columns per work-item at K = 1024 -- the generic gradient
     kernel and the 32-column register form of update_phi / perplexity.  Must run, learn and print every category."""
     g, d = str(tmp_path / "g.txt"), str(tmp_path / "g.bin.gz")
-    _snap_file(g, N=6000, deg=16)
+    _snap_file(g, N=12000, deg=16)  # (device sampling wants N >= 2 m plus the largest degree)
     r = subprocess.run([exe, "-f", g, "--dump-data", "1", "--dump-file", d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     run = subprocess.run([exe, "--load-data", "1", "--load-file", d, "-k", "1024", "-m", "4096", "-x", "40", "-i", "20"]
