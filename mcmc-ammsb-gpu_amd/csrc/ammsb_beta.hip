@@ -281,9 +281,13 @@ typedef const __attribute__((address_space(1))) void beta_glb_void_t;
 // division per column: update_pi_kernel<64, KPT>'s arithmetic -- and written to pi (+ phi_sum), so every pi row of
 // the mini-batch is written exactly once (the shared node's by slot 0) and what the gradient multiplies are the
 // values the separate update_pi would have stored: bit-identical, one launch and one pass over the rows less.
-template <int KPT, int W, bool FUSE = false>
+// VL = 32 (W == 1): the reference work-group size is 32 (its default, main.cc:64); the slot keeps its whole wave, the
+// WG_SUM chains / trees follow the 32 virtual lanes (VLane<32>, ammsb_dev.h).
+template <int KPT, int W, bool FUSE = false, int VL = 64>
 __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a) {
   static_assert(!FUSE || W == 1, "the fused form is one wave per slot");
+  static_assert(VL == 64 || W == 1, "virtual half-wave lanes only for one-wave slots");
+  using VLn = VLane<VL>;
   // L = 64 W lanes per slot: wave wv owns columns 64 wv + ln + L j (the slicing of update_phi_lds_kernel); every
   // wave streams its own slice of the rows, the two WG_SUMs of an edge share one LDS exchange and one barrier.
   constexpr int L = 64 * W;
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   // WG_SUM over L lanes (sum.cc:20-29) of two values at once
   auto group_sum2 = [&](float& v0, float& v1) {
     if constexpr (W == 1) {
-      v0 = Group<64>::wave_tree64(v0);
-      v1 = Group<64>::wave_tree64(v1);
+      v0 = VLn::tree(v0);
+      v1 = VLn::tree(v1);
     } else {
       float* x = xsum + phase * 2 * L;
       phase ^= 1;
@@ -411,10 +415,10 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
       pa[p] = f32x2{src[tid + 2 * L * p], src[tid + 2 * L * p + L]};
-      partial += pa[p].x;
-      partial += pa[p].y;
+      VLn::chain(partial, pa[p].x);
+      VLn::chain(partial, pa[p].y);
     }
-    const float sum = Group<64>::wave_tree64(partial);
+    const float sum = VLn::tree(partial);
     float* dst = rpm_row(a.pi, shared_node);
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
@@ -469,10 +473,10 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
         pbn[p] = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
-        partial += pbn[p].x;
-        partial += pbn[p].y;
+        VLn::chain(partial, pbn[p].x);
+        VLn::chain(partial, pbn[p].y);
       }
-      const float sum = Group<64>::wave_tree64(partial);
+      const float sum = VLn::tree(partial);
       float* dst = rpm_row(a.pi, partner);
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
@@ -496,13 +500,13 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       if constexpr (FUSE) pb = pbn[p];
       else pb = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
       const f32x2 f = pa[p] * pb;
-      scratch += f.x;
-      scratch += f.y;
+      VLn::chain(scratch, f.x);
+      VLn::chain(scratch, f.y);
       const f32x2 pr = (y ? bk[p] : 1.0f - bk[p]) * f;
       row_b[ln + 128 * p] = pr.x;
       row_b[ln + 128 * p + 64] = pr.y;
-      ppart += pr.x;
-      ppart += pr.y;
+      VLn::chain(ppart, pr.x);
+      VLn::chain(ppart, pr.y);
       const float m0 = fabsf(pr.x), m1 = fabsf(pr.y);
       lo = fminf(fminf(lo, m0 == 0.0f ? 1.0f : m0), m1 == 0.0f ? 1.0f : m1);  // an exact zero divides exactly
     }
@@ -541,20 +545,20 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   }
 }
 
-template <int KPT, int W>
+template <int KPT, int W, int VL = 64>
 int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   const size_t lds = (size_t)W * 4 * sizeof(float) * 64 * KPT;
-  static const std::string name = ammsb_kname("beta_grads_lds_kernel<%d, %d, false>", KPT, W);
-  static const std::string name_fused = ammsb_kname("beta_grads_lds_kernel<%d, %d, true>", KPT, W);
+  static const std::string name = ammsb_kname("beta_grads_lds_kernel<%d, %d, false, %d>", KPT, W, VL);
+  static const std::string name_fused = ammsb_kname("beta_grads_lds_kernel<%d, %d, true, %d>", KPT, W, VL);
   ctx->kernel_name[AMMSB_KN_GRADS] = (a.fuse.phi_vec ? name_fused : name).c_str();
   if constexpr (W == 1) {
     if (a.fuse.phi_vec) {
-      beta_grads_lds_kernel<KPT, 1, true><<<a.P, 64, lds, s>>>(a);
+      beta_grads_lds_kernel<KPT, 1, true, VL><<<a.P, 64, lds, s>>>(a);
       AMMSB_LAUNCH_CHECK(ctx);
       return AMMSB_OK;
     }
   }
-  beta_grads_lds_kernel<KPT, W><<<a.P, 64 * W, lds, s>>>(a);
+  beta_grads_lds_kernel<KPT, W, false, VL><<<a.P, 64 * W, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -978,14 +982,14 @@ static bool beta_fuse_shape(ammsb_ctx* ctx, uint32_t wg) {
   static const bool off = [] {
     const char* f = getenv("AMMSB_BETA_FORM");
     const char* g = getenv("AMMSB_LOOP_FUSE_PI");
-    return (f && f[0] == 'r') || (g && atoi(g) == 0);
+    return (f && (f[0] == 'r' || f[0] == 'g')) || (g && atoi(g) == 0);
   }();
   // K = 1024 is built and tested too (AMMSB_LOOP_FUSE_PI=2) but not taken by default: at C3 the step time does not
   // change (the gradient kernel is latency-bound per wave and the normalisation lands on its critical path), while the
   // shorter main chain moves more of the concurrent sampling chain under update_phi
   static const bool k1024 = getenv("AMMSB_LOOP_FUSE_PI") && atoi(getenv("AMMSB_LOOP_FUSE_PI")) == 2;
   if (off) return false;
-  if (wg == 64 && (K == 256 || K == 512 || (K == 1024 && k1024))) return true;  // beta_grads_lds_kernel<KPT, 1, true>
+  if ((wg == 64 || wg == 32) && (K == 256 || K == 512 || (K == 1024 && k1024))) return true;  // beta_grads_lds_kernel<KPT, 1, true, wg>
   return (wg == 32 || wg == 64) && K <= 2 * wg;                                   // beta_grads_kernel<L, 1 | 2, true>
 }
 
@@ -1043,7 +1047,7 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.fuse = ammsb_pi_fusion{nullptr, nullptr, nullptr, nullptr};
   if (fuse && fuse->phi_vec) {
     AMMSB_CHECK_ARG(ctx, desc && fuse->phi_sum && fuse->nodes && beta_fuse_shape(ctx, wg),
-                    "update_pi fusion needs a descriptor and an LDS-kernel shape at wg 64");
+                    "update_pi fusion needs a descriptor and a shape the fused kernels take");
     a.fuse = *fuse;
   }
   const uint32_t span = edge_end - edge_begin;
@@ -1063,7 +1067,13 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   // lane for longer rows (K = 4096: wg 256)
   bool launched = false;
   int rc = AMMSB_OK;
-  if (generic) {
+  if (wg == 32 && !force_reg && !force_gen && pi->num_cols % 4 == 0 && (K == 256 || K == 512 || K == 1024)) {
+    // the reference's default work-group size on the LDS-streamed one-wave-per-slot kernels (VLane<32>)
+    launched = true;
+    if (K == 256) rc = launch_grads_lds<4, 1, 32>(ctx, a, s);
+    else if (K == 512) rc = launch_grads_lds<8, 1, 32>(ctx, a, s);
+    else rc = launch_grads_lds<16, 1, 32>(ctx, a, s);
+  } else if (generic) {
     launched = true;
     rc = launch_grads_gen(ctx, a, wg, s);
   } else if (!force_reg && K == wg * (uint32_t)kpt && pi->num_cols % 4 == 0) {

@@ -330,6 +330,50 @@ struct Group {
 
 inline __host__ __device__ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
+// ------------------------------------------------------------- 32 virtual lanes in one wave64
+// The LDS-streamed kernels give a node (an edge slot) one whole wave: physical lane p owns columns p + 64 i.  The
+// reference's DEFAULT work-group size is 32 (main.cc:61-64): virtual lane l owns columns l + 32 j, i.e. the columns of
+// physical lanes l (even j = 2 i) and l + 32 (odd j = 2 i + 1).  The elementwise work does not care who owns a column;
+// WG_SUM does: lane l's partial is the chain ((0 + x[l]) + x[l + 32]) + x[l + 64] ... in ascending j (sum.cc:20-22),
+// which alternates between the two physical lanes.  v_permlane32_swap hands every lane both values of a column pair
+// position (in all 64 lanes: t[0] = the lower half's, t[1] = the upper half's), so both halves run the identical
+// chain -- twice the dependent adds of the 64-lane form, no LDS traffic -- and the tree over the 32 virtual lanes is
+// wave_tree64 without its first level (the halves hold the same values).  VL = 64 is the plain one-column-per-add form.
+template <int VL>
+struct VLane {
+  static_assert(VL == 32 || VL == 64, "virtual lanes per wave");
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  // acc += the next column(s) of this lane's virtual lane, in the reference's order
+  __device__ __forceinline__ static void chain(float& acc, float v) {
+    if constexpr (VL == 64) {
+      acc += v;
+    } else {
+      const u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      acc += __uint_as_float(t[0]);
+      acc += __uint_as_float(t[1]);
+    }
+  }
+  // the halving tree over the VL lane partials (sum.cc:23-29), result in every lane
+  __device__ __forceinline__ static float tree(float v) {
+    if constexpr (VL == 64) {
+      return Group<64>::wave_tree64(v);
+    } else {
+      u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));  // row_shl:8
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));  // row_shl:4
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));  // row_shl:2
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));  // row_shl:1
+      return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+    }
+  }
+  // stream / virtual lane of physical lane `tid`, and whether this lane keeps the virtual lane's draw number j
+  // (VL = 64: the thread's own index within its node's group, which may span several waves)
+  __device__ __forceinline__ static int vlane(int tid) { return VL == 64 ? tid : (tid & (VL - 1)); }
+  __device__ __forceinline__ static bool keeps(int tid, uint32_t j) { return VL == 64 || (j & 1u) == (uint32_t)(tid >> 5); }
+  static constexpr int PER = 64 / VL;  // virtual columns per physical column: draw j belongs to physical column j / PER
+};
+
 // ----------------------------------------------------------------- virtual group sum (any K / L)
 // The generic kernels (the shapes no specialised kernel takes: more columns per reference work-item than fit a lane's
 // registers -- K = 1024 at the reference's default work-group size 32 for the gradient, K = 4096 at 32 for all three)

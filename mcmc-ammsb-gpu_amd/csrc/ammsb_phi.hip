@@ -373,9 +373,16 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // else -- 2 x (3 x 4 KiB + 128 B) + 1.5 KiB = 26 368 B puts six such blocks = TWELVE waves on a CU where the one-node
 // block (13 956 B) fits eleven times.  The waves never wait for each other after the table load (wave-local LDS
 // ordering instead of block barriers: their node counts may differ).
-template <int KPT, int W, int D = 2, int NB = 1>
+// VL = 32 (only with W == 1): the reference work-group size is 32, not 64 -- the node still gets the whole wave and
+// every lane its 64-strided columns; the WG_SUM chain / tree and the stream-to-column map follow the 32 virtual lanes
+// (VLane<32>, ammsb_dev.h).  K = 1024 at the reference's default phi_wg_size (main.cc:61) takes this form.
+template <int KPT, int W, int D = 2, int NB = 1, int VL = 64>
 __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT <= 4 ? AMMSB_PHI_WPE4 : KPT <= 8 ? AMMSB_PHI_WPE8 : KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
   static_assert(NB == 1 || W == 1, "several nodes per block only for one-wave nodes");
+  static_assert(VL == 64 || W == 1, "virtual half-wave lanes only for one-wave nodes");
+  using VLn = VLane<VL>;
+  constexpr int LV = VL == 64 ? 64 * W : VL;  // the reference work-group size: streams per node
+  constexpr int KV = KPT * VLn::PER;          // columns (= normals) per virtual lane
   // L = 64 W lanes per node: wave wv owns columns 64 wv + ln + L j, i.e. KPT chunks of 64 consecutive floats per
   // row.  Each wave runs the single-wave pipeline on its own slice (own ring, own waits); the only cross-wave
   // step is the WG_SUM of a neighbour's probs: one LDS exchange and one barrier per row.
@@ -432,7 +439,16 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
     beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
   }
   ammsb_seed rs = {0, 0};
-  if (a.noise_on) rs = a.seeds[(uint64_t)g * L + tid];
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * LV + VLn::vlane(tid)];  // (VL = 32: both halves carry the same stream)
+  // the virtual lane's normal number j scales the noise slot of physical column j / PER in the lane that owns it
+  auto draw_normal = [&](uint32_t j) {
+    if constexpr (VL == 64) {
+      s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
+    } else {
+      const float z = rng_normal(rs, &zig);
+      if (VLn::keeps(tid, j)) s_noise[ln + 64 * (j / VLn::PER)] = s_noise[ln + 64 * (j / VLn::PER)] * z;
+    }
+  };
 
   // request this wave's slice of neighbour row q into ring slot `slot`: piece t carries chunks j = 4t .. 4t+3
   // (16 lanes x 16 B each), so the slice lands as [j][64] and lane ln reads column tid + L j at [j * 64 + ln]
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
   int phase = 0;
   auto group_sum = [&](float v) -> float {
     if constexpr (W == 1) {
-      return Group<64>::wave_tree64(v);
+      return VLn::tree(v);
     } else {
       float* x = xsum + phase * L;
       phase ^= 1;
@@ -512,11 +528,11 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
         request(q + (D - 1), (q + (D - 1)) & (D - 1));
         // one of the lane's KPT normals per iteration, drawn while row q is still on its way (stream order is
         // the ascending column order of the SGLD step below)
-        if (a.noise_on && q < (uint32_t)KPT) s_noise[ln + 64 * q] = s_noise[ln + 64 * q] * rng_normal(rs, &zig);
+        if (a.noise_on && q < (uint32_t)KV) draw_normal(q);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PIECES) : "memory");  // row q landed, D-1 rows in flight
       } else {
         if constexpr (D > 2) {  // (D == 2 keeps the round-1 instruction stream: the last row draws no normal)
-          if (a.noise_on && q < (uint32_t)KPT) s_noise[ln + 64 * q] = s_noise[ln + 64 * q] * rng_normal(rs, &zig);
+          if (a.noise_on && q < (uint32_t)KV) draw_normal(q);
         }
         // the tail: rows q+1 .. n-1 (fewer than D-1) are still in flight
         const uint32_t rem = n - 1 - q;
@@ -553,8 +569,8 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
           const f32x2 pr = pi_a[p] * tt;
           row[ln + 128 * p] = pr.x;
           row[ln + 128 * p + 64] = pr.y;
-          partial += pr.x;
-          partial += pr.y;
+          VLn::chain(partial, pr.x);
+          VLn::chain(partial, pr.y);
           lo = fminf(fminf(lo, fabsf(pr.x)), fabsf(pr.y));
         }
       };
@@ -591,8 +607,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
     // normals the loop did not get to (n - 1 < KPT): one rolled loop, a single copy of the ziggurat code
     if (a.noise_on) {
 #pragma unroll 1
-      for (uint32_t j = D > 2 ? n : (n > 0 ? n - 1 : 0); j < (uint32_t)KPT; ++j)
-        s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
+      for (uint32_t j = D > 2 ? n : (n > 0 ? n - 1 : 0); j < (uint32_t)KV; ++j) draw_normal(j);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -614,7 +629,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
       __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
     }
   }
-  if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
+  if (a.noise_on && tid < LV) a.seeds[(uint64_t)g * LV + tid] = rs;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -628,9 +643,12 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
 // multiplication by +-1, which is exact, instead of two code copies), so the scheduler interleaves two independent
 // chains per wave.  Every value is computed by the same operations in the same order as in the single-row kernel:
 // results are bit-identical (same tests).  Needs an even n; odd n takes the single-row kernel.
-template <int KPT, int D, int U>
+// VL = 32: the reference work-group size 32 in the same one-wave-per-node layout (see update_phi_lds_kernel).
+template <int KPT, int D, int U, int VL = 64>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void update_phi_lds2_kernel(const PhiArgs a) {
   constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
+  using VLn = VLane<VL>;
+  constexpr int KV = KPT * VLn::PER;  // columns (= normals) per virtual lane
   // probs[] of the U rows in flight stay in registers when that is at most 16 of them per lane (K = 256: 4 rows x 4
   // columns, K = 512: 2 x 8): no write-back into the ring slot and re-read between the two passes
   constexpr bool REGP = U * HP <= 8;
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
     beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
   }
   ammsb_seed rs = {0, 0};
-  if (a.noise_on) rs = a.seeds[(uint64_t)g * L + tid];
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * VL + VLn::vlane(tid)];
 
   auto request = [&](uint32_t q, uint32_t slot) {
     const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
@@ -731,12 +749,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
         if constexpr (REGN) {
           if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < U; ++r) nz[r] = nz[r] * rng_normal(rs, &zig);
+            for (int j = 0; j < KV; ++j) {
+              const float z = rng_normal(rs, &zig);
+              if (VLn::keeps(tid, (uint32_t)j)) nz[j / VLn::PER] = nz[j / VLn::PER] * z;
+            }
           }
         } else {
 #pragma unroll
           for (int r = 0; r < U; ++r)
-            if (q + r < (uint32_t)KPT) s_noise[ln + 64 * (q + r)] = s_noise[ln + 64 * (q + r)] * rng_normal(rs, &zig);
+            if (q + r < (uint32_t)KV) {
+              const float z = rng_normal(rs, &zig);
+              const uint32_t c = (q + r) / VLn::PER;
+              if (VLn::keeps(tid, q + r)) s_noise[ln + 64 * c] = s_noise[ln + 64 * c] * z;
+            }
         }
       }
       {  // rows q .. q+U-1 landed; rows q+U .. min(q+D-1, n-1) may still be in flight (a multiple of U of them)
@@ -773,14 +798,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
             row[r][ln + 128 * p] = pr.x;
             row[r][ln + 128 * p + 64] = pr.y;
           }
-          part[r] += pr.x;
-          part[r] += pr.y;
+          VLn::chain(part[r], pr.x);
+          VLn::chain(part[r], pr.y);
           lo[r] = fminf(fminf(lo[r], fabsf(pr.x)), fabsf(pr.y));
         }
       }
 #pragma unroll
       for (int r = 0; r < U; ++r) {
-        psum[r] = Group<64>::wave_tree64(part[r]);  // phi.cc:254-257
+        psum[r] = VLn::tree(part[r]);  // phi.cc:254-257
         fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
         all_fast = all_fast && fast[r];
       }
@@ -852,7 +877,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
     if constexpr (!REGN) {  // (REGN: n >= U == KPT, the first row group drew them all)
       if (a.noise_on) {
 #pragma unroll 1
-        for (uint32_t j = n; j < (uint32_t)KPT; ++j) s_noise[ln + 64 * j] = s_noise[ln + 64 * j] * rng_normal(rs, &zig);
+        for (uint32_t j = n; j < (uint32_t)KV; ++j) {
+          const float z = rng_normal(rs, &zig);
+          if (VLn::keeps(tid, j)) s_noise[ln + 64 * (j / VLn::PER)] = s_noise[ln + 64 * (j / VLn::PER)] * z;
+        }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -877,25 +905,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
     }
   }
-  if (a.noise_on) a.seeds[(uint64_t)g * L + tid] = rs;
+  if (a.noise_on && tid < VL) a.seeds[(uint64_t)g * VL + tid] = rs;
 }
 
-template <int KPT, int D, int U>
+template <int KPT, int D, int U, int VL = 64>
 int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
-  static const std::string name = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d>", KPT, D, U);
+  static const std::string name = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d, %d>", KPT, D, U, VL);
   ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
-  update_phi_lds2_kernel<KPT, D, U><<<n_groups, 64, lds, s>>>(a);
+  update_phi_lds2_kernel<KPT, D, U, VL><<<n_groups, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
 
-template <int KPT, int W, int D = 2, int NB = 1>
+template <int KPT, int W, int D = 2, int NB = 1, int VL = 64>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t per_node = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + ((sizeof(uint32_t) * a.n + 15) & ~(size_t)15);
-  static const std::string name = ammsb_kname("update_phi_lds_kernel<%d, %d, %d, %d>", KPT, W, D, NB);
+  static const std::string name = ammsb_kname("update_phi_lds_kernel<%d, %d, %d, %d, %d>", KPT, W, D, NB, VL);
   ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
-  update_phi_lds_kernel<KPT, W, D, NB><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
+  update_phi_lds_kernel<KPT, W, D, NB, VL><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1268,11 +1296,26 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   if (a.group_begin >= a.group_end) return AMMSB_OK;
   const uint32_t n_groups = a.group_end - a.group_begin;
   hipStream_t s = as_stream(stream);
-  if (generic) return launch_phi_gen(ctx, a, wg, n_groups, s);
   static const bool force_reg = [] {
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
   }();
+  // The reference's default work-group size (32, main.cc:61) on rows of 256 .. 2048 columns: 32 virtual lanes in the
+  // one-wave-per-node LDS-streamed kernels (VLane<32>); K / 32 columns per work-item = 2 x the columns per physical lane
+  if (wg == 32 && !force_reg && !force_gen && pi->num_cols % 4 == 0 && a.n * sizeof(uint32_t) <= 8192) {
+    switch (p.K) {
+      case 256:
+        if (a.n & 1) return launch_phi_lds<4, 1, 8, 1, 32>(ctx, a, n_groups, s);
+        if (a.n & 3) return launch_phi_lds2<4, 8, 2, 32>(ctx, a, n_groups, s);
+        return launch_phi_lds2<4, 8, 4, 32>(ctx, a, n_groups, s);
+      case 512:
+        if (a.n & 1) return launch_phi_lds<8, 1, 4, 1, 32>(ctx, a, n_groups, s);
+        return launch_phi_lds2<8, 4, 2, 32>(ctx, a, n_groups, s);
+      case 1024: return launch_phi_lds<16, 1, 2, 1, 32>(ctx, a, n_groups, s);
+      case 2048: return launch_phi_lds<32, 1, 2, 1, 32>(ctx, a, n_groups, s);
+    }
+  }
+  if (generic) return launch_phi_gen(ctx, a, wg, n_groups, s);
   // LDS-streamed kernels: K == wg * kpt exactly.  One wave per node up to K = 2048 (wg 64); for longer rows the
   // node is spread over wg / 64 waves with 16 columns per lane (K = 4096: wg 256, K = 8192: wg 512, ...).
   if (!force_reg && p.K == (uint64_t)wg * kpt && pi->num_cols % 4 == 0 && a.n * sizeof(uint32_t) <= 8192) {

@@ -135,9 +135,10 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void ppx_kernel(const PpxArgs a) {
 typedef __attribute__((address_space(3))) void ppx_lds_void_t;
 typedef const __attribute__((address_space(1))) void ppx_glb_void_t;
 
-template <int KPT, uint32_t D>
+// VL = 32: the reference's default ppx_wg_size (main.cc:63) on the same one-wave-per-slot layout (VLane<32>).
+template <int KPT, uint32_t D, int VL = 64>
 __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
-  using Grp = Group<64>;
+  using VLn = VLane<VL>;
   constexpr int K = 64 * KPT, HP = KPT / 2, PIECES = KPT / 4;
   extern __shared__ __align__(16) char smem[];  // [D edges][2 rows][K] floats
   float* ring = reinterpret_cast<float*>(smem);
@@ -152,7 +153,6 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
   unsigned long long c_link = 0, c_non = 0;
   const uint32_t n_edges = a.edge_end - a.edge_begin;
   const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // wave-uniform
-  int phase = 0;
   const float cm1 = (float)(a.call_count - 1), cc = (float)a.call_count;
 
   auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
@@ -220,14 +220,14 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
       const f32x2 pa = f32x2{row_a[l + 128 * p], row_a[l + 128 * p + 64]};
       const f32x2 pb = f32x2{row_b[l + 128 * p], row_b[l + 128 * p + 64]};
       const f32x2 f = pa * pb;
-      f_part += f.x;
-      f_part += f.y;
+      VLn::chain(f_part, f.x);
+      VLn::chain(f_part, f.y);
       const f32x2 w = f * (y ? bk[p] : 1.0f - bk[p]);
-      s_part += w.x;
-      s_part += w.y;
+      VLn::chain(s_part, w.x);
+      VLn::chain(s_part, w.y);
     }
-    const float fsum = Grp::sum(f_part, (float*)nullptr, phase);
-    float s = Grp::sum(s_part, (float*)nullptr, phase);
+    const float fsum = VLn::tree(f_part);
+    float s = VLn::tree(s_part);
     if (!y) {
       const float tt = 1.0f - fsum;
       const float u1 = 1.0f - a.epsilon;
@@ -383,14 +383,14 @@ int launch_ppx_gen(ammsb_ctx* ctx, const PpxArgs& a, uint32_t wg, hipStream_t s)
   return AMMSB_OK;
 }
 
-template <int KPT>
+template <int KPT, int VL = 64>
 int launch_ppx_lds(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
   // two-edge ring: 16 KiB per wave, so the 8 slots per CU the launch asks for are resident at once (a three-edge
   // ring at 24 KiB fits 6 and needs a second round: 0.335 vs 0.250 ms at C3; 1536 slots x 3 edges ties at 0.247)
   const size_t lds = (size_t)2 * 2 * sizeof(float) * 64 * KPT;
-  static const std::string name = ammsb_kname("ppx_lds_kernel<%d, 2u>", KPT);
+  static const std::string name = ammsb_kname("ppx_lds_kernel<%d, 2u, %d>", KPT, VL);
   ctx->kernel_name[AMMSB_KN_PPX] = name.c_str();
-  ppx_lds_kernel<KPT, 2><<<a.P, 64, lds, s>>>(a);
+  ppx_lds_kernel<KPT, 2, VL><<<a.P, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -520,6 +520,8 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
   a.epsilon = ctx->params.epsilon;
   const uint32_t span = edge_end - edge_begin;
   uint32_t want = (uint32_t)ctx->num_cus * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
+  // (the one-wave-per-slot LDS form at wg 32 wants the slot count of the wg 64 form: 8 resident waves per CU)
+  if (wg == 32 && (K == 256 || K == 512 || K == 1024) && pi->num_cols % 4 == 0) want = (uint32_t)ctx->num_cus * 8u;
   if (want < 64) want = 64;
   if (want > ctx->max_ppx_blocks) want = ctx->max_ppx_blocks;
   a.P = span < want ? span : want;
@@ -527,7 +529,14 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
     const char* f = getenv("AMMSB_PPX_FORM");
     return f && f[0] == 'r';
   }();
-  if (generic) {
+  if (wg == 32 && !force_reg && !force_gen && pi->num_cols % 4 == 0 && (K == 256 || K == 512 || K == 1024)) {
+    // the reference's default work-group size on the LDS-streamed one-wave-per-slot kernel (VLane<32>)
+    int rc = AMMSB_OK;
+    if (K == 256) rc = launch_ppx_lds<4, 32>(ctx, a, s);
+    else if (K == 512) rc = launch_ppx_lds<8, 32>(ctx, a, s);
+    else rc = launch_ppx_lds<16, 32>(ctx, a, s);
+    if (rc) return rc;
+  } else if (generic) {
     const int rc = launch_ppx_gen(ctx, a, wg, s);
     if (rc) return rc;
   } else if (wg == 64 && !force_reg && K == 64u * (uint32_t)kpt && kpt >= 4 && kpt <= 16 && pi->num_cols % 4 == 0) {

@@ -125,7 +125,7 @@ def test_cli_run_load_and_resume(exe, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("loop", [[], ["--async", "1", "--device-sampling", "1"], ["--graph", "1", "--device-sampling", "1"]])
+@pytest.mark.parametrize("loop", [[], ["--async", "1", "--device-sampling", "1"], ["--async", "1", "--graph", "1", "--device-sampling", "1"]])
 def test_cli_reference_default_work_groups_at_k1024(exe, tmp_path, loop):
     """`ammsb_main -k 1024 -m 4096` with NO work-group flags: the reference's defaults are 32 for phi, beta, perplexity
     and the neighbour sampler (main.cc:61-64), i.e. 32 columns per work-item at K = 1024 -- the generic gradient

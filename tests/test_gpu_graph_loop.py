@@ -53,6 +53,10 @@ def _same(a, b):
                                               (96, 64, 256, "Node"),      # K not a multiple of the work-group: column guards
                                               (128, 64, 256, "NodeLink"),  # two columns per lane, register kernels
                                               (512, 64, 300, "Node"),     # <8, 1>: update_pi folded into the gradient
+                                              (256, 32, 512, "Node"),     # the reference's default wg: 32 virtual lanes per wave, fused
+                                              (512, 32, 300, "Node"),
+                                              (1024, 32, 200, "Node"),    # <16, 1, ..., 32>, separate update_pi
+                                              (2048, 32, 150, "Node"),    # phi <32, 1, 2, 1, 32>, generic gradient kernel
                                               (1024, 64, 200, "Node")])   # <16, 1>: the C3 kernels (fusion opt-in, below)
 def test_graph_loop_equals_eager_loop(env, small_ds, K, wg, m, strategy):
     ops, hostlib, learner, torch = env

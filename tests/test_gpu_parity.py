@@ -295,6 +295,15 @@ PHI_CASES = [
     (512, 4096, 5, 16, 64),     # 64 columns per work-item
     (300, 8192, 3, 6, 128),     # generic kernel, 16 columns per thread, tree levels through LDS
     (600, 3000, 6, 20, 16),     # K not a multiple of anything, 188 columns per work-item
+    # the reference's default work-group size (32) on the one-wave-per-node LDS kernels: 32 virtual lanes per wave
+    (2048, 256, 32, 200, 32),   # update_phi_lds2_kernel<4, 8, 4, 32>
+    (2048, 256, 6, 100, 32),    # <4, 8, 2, 32>
+    (2048, 256, 5, 100, 32),    # odd n: update_phi_lds_kernel<4, 1, 8, 1, 32>
+    (2048, 256, 2, 100, 32),    # fewer neighbours than normals per virtual lane
+    (2048, 512, 32, 100, 32),   # update_phi_lds2_kernel<8, 4, 2, 32>
+    (2048, 512, 7, 100, 32),    # update_phi_lds_kernel<8, 1, 4, 1, 32>
+    (512, 2048, 8, 40, 32),     # update_phi_lds_kernel<32, 1, 2, 1, 32>: 64 columns per work-item
+    (512, 2048, 70, 20, 32),    # more neighbours than normals per virtual lane
 ]
 
 
@@ -417,7 +426,8 @@ BETA_CASES = [(2048, 64, 500, 64), (2048, 64, 500, 32), (2048, 256, 3000, 128), 
               (1024, 4096, 1300, 256), (1024, 2048, 300, 128),  # LDS-streamed kernel with 4 / 2 waves per slot
               (4096, 1024, 1024, 32),   # wg-beta-test.cc:152-154 at the reference's default beta_wg_size (main.cc:64)
               (1024, 4096, 700, 32), (1024, 4096, 700, 128),   # C5 rows: 128 / 32 columns per work-item (generic kernel)
-              (1024, 2048, 300, 64), (300, 8192, 200, 256), (600, 3000, 500, 16)]
+              (1024, 2048, 300, 64), (300, 8192, 200, 256), (600, 3000, 500, 16),
+              (2048, 256, 3000, 32), (2048, 512, 500, 32), (2048, 256, 9000, 32)]  # wg 32 on the LDS-streamed kernels
 
 
 @pytest.mark.parametrize("N,K,n_edges,L", BETA_CASES)
@@ -472,7 +482,8 @@ def test_beta_grads_edge_shards(orc, hip):
 
 @pytest.mark.parametrize("N,K,L", [(1024, 1024, 64), (1024, 1024, 256), (1024, 1024, 1024), (2048, 96, 32),
                                    (2048, 1000, 128), (1024, 1024, 32),   # the default ppx_wg_size (main.cc:63)
-                                   (512, 4096, 32), (512, 4096, 64), (300, 8192, 128), (600, 3000, 16)])  # generic kernel
+                                   (512, 4096, 32), (512, 4096, 64), (300, 8192, 128), (600, 3000, 16),  # generic kernel
+                                   (2048, 256, 32), (2048, 512, 32)])  # wg 32 on the LDS-streamed kernel
 def test_perplexity(orc, hip, N, K, L):
     # wg-perplexity-test.cc:86-108 shape: N=1024, K=1024, ~1024 held-out edges
     pr = Problem(orc, hip, N, K, 8, 16)
