@@ -373,7 +373,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
             (st[:, 2] >= st[:, 1]) & (st[:, 1] >= st[:, 0])
         if ok.any():
             d = lambda a, b: float((st[ok, b] - st[ok, a]).mean()) * 1e-9  # noqa: E731  (seconds)
-            fused = names["beta_grads"].endswith("true>")  # update_pi folded into the gradient kernel (<..., FUSE = true>)
+            fused = ", true" in names["beta_grads"]  # update_pi folded into the gradient kernel (<..., FUSE = true, ...>)
             nodes = m + 1
             b_phi = phi_bytes_per_node(K, n) * nodes
             b_pi = (8 * K + 8) * nodes

@@ -908,6 +908,279 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
   if (a.noise_on && tid < VL) a.seeds[(uint64_t)g * VL + tid] = rs;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Short rows, TWO NODES PER WAVE (K = 32 KPT: 256 / 512; reference work-group size VL = 32 or 64; n % U == 0).
+//
+// At K = 256 a node is 32 KB of rows and its wave spends most of its instructions on what does not scale with the row:
+// the WG_SUM tree, the reciprocal, the range checks, the ring bookkeeping, the waits (SQ counters, DESIGN.md 4.7: 88
+// vector instructions per neighbour row per wave, 43 % of a wave's life parked on s_waitcnt).  Here each HALF of the
+// wave owns a node: physical lane l of half h holds columns l + 32 j of node h's rows, so every instruction of the
+// tree / reciprocal / bookkeeping serves two nodes, and a CU holds twice the nodes per resident wave.
+//   VL = 32: physical lane l IS the reference's work-item l (columns l + 32 j): its lane partial is the plain chain.
+//   VL = 64: physical lane l carries the reference's work-items l (even j: columns l + 64 i) and l + 32 (odd j): two
+//            lane partials, whose sum is the first level of the reference's tree (aux[l] += aux[l + 32], sum.cc:23-29),
+//            and two RNG streams.
+// The five remaining tree levels run on both halves at once (v_permlane16_swap + DPP row shifts stay inside 32-lane
+// halves / 16-lane rows).  A neighbour row pair travels as PIECES LDS-DMA instructions of 512 B per half.  Link flags,
+// neighbour ids and the fast / slow division choice are per half, i.e. per-lane values here, not wave-uniform ones.
+// Same operations in the same order on every value as update_phi_lds2_kernel / update_phi_kernel: bit-identical.
+template <int KPT, int D, int U, int VL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 8 ? 4 : 3))) void update_phi_pair_kernel(const PhiArgs a) {
+  constexpr int K = 32 * KPT, HP = KPT / 2, PIECES = KPT / 4, SLOT = 2 * K;  // SLOT: floats of one ring slot (both halves)
+  constexpr int NS = VL / 32;  // reference work-items (lane partials, RNG streams) per physical lane
+  static_assert((VL == 32 || VL == 64) && D > U && (D & (D - 1)) == 0 && (U == 2 || U == 4) && (D - U) * PIECES <= 63, "shape");
+  extern __shared__ __align__(16) char smem[];  // [D][PIECES][2 halves][128] ring, [2][K] noise, [2][n] u32 (id | link bit)
+  __shared__ ZigTables zig;
+  const int tid = threadIdx.x, h = tid >> 5, l = tid & 31;
+  float* ring = reinterpret_cast<float*>(smem);
+  float* s_nz = ring + D * SLOT + h * K + l;  // this lane's noise factors: column l + 32 j at [32 j]
+  const uint32_t n = a.n;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + (size_t)(D + 1) * SLOT * sizeof(float)) + h * n;  // this half's list
+  // column l + 32 j of this half's row in a slot: piece j / 4, then [half][128]
+  auto lds_col = [&](int j) -> int { return (j >> 2) * 256 + h * 128 + l + 32 * (j & 3); };
+
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
+  const uint32_t g = a.group_begin + blockIdx.x * 2 + h;  // this half's virtual group
+  const bool live = g < st.group_end;
+  if (!__builtin_amdgcn_readfirstlane((int)(a.group_begin + blockIdx.x * 2 < st.group_end))) return;  // neither half
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  f32x2 bf[HP];
+  bool beta_safe = true;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    const float b0 = a.beta[2 * (l + 64 * p) + 1];
+    const float b1 = a.beta[2 * (l + 64 * p + 32) + 1];
+    bf[p] = f32x2{b0 - EPS, b1 - EPS};
+    beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
+  }
+  ammsb_seed rs[NS];
+#pragma unroll
+  for (int v = 0; v < NS; ++v) {
+    rs[v] = ammsb_seed{0, 0};
+    if (live && a.noise_on) rs[v] = a.seeds[(uint64_t)g * VL + l + 32 * v];
+  }
+
+  // the halving tree over one half's 32 lane values (levels 16 .. 1), both halves at once; result in every lane
+  auto tree32 = [&](float v) -> float {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));  // row_shl:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));  // row_shl:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));  // row_shl:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));  // row_shl:1
+    const float s0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+    const float s1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+    return h ? s1 : s0;
+  };
+
+  // row q of each half's neighbour list into ring slot `slot` (512 B per half and piece)
+  // a row base per half from two scalar address computations (a per-lane rpm_row would carry a 64-bit division)
+  auto half_row = [&](uint32_t id) -> const float* {
+    const float* r0 = rpm_row(a.pi, __builtin_amdgcn_readlane(id, 0));
+    const float* r1 = rpm_row(a.pi, __builtin_amdgcn_readlane(id, 32));
+    return h ? r1 : r0;
+  };
+  auto request = [&](uint32_t q, uint32_t slot) {
+    const float* src = half_row(s_nb[q] & 0x7fffffffu) + 4 * l;
+    char* dst = smem + (size_t)slot * (SLOT * sizeof(float));
+#pragma unroll
+    for (int t = 0; t < PIECES; ++t)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 128 * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+  };
+
+  const uint32_t trips = (st.n_nodes + st.G - 1) / st.G;  // wave-uniform
+  for (uint32_t t = 0; t < trips; ++t) {
+    const uint64_t i_raw = (uint64_t)g + (uint64_t)t * st.G;
+    const bool on = live && i_raw < st.n_nodes;
+    if (!__builtin_amdgcn_readfirstlane((int)(__ballot(on) != 0ull))) continue;  // no half has a node in this trip
+    const uint64_t i = on ? i_raw : 0;  // an idle half shadows node 0 and stores nothing
+    const uint32_t node = a.nodes[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order)
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t q = l; q < n; q += 32) s_nb[q] = a.neighbors[i * n + q];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    const float phi_sum = a.phi_sum[node];
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = half_row(node);
+    f32x2 pi_a[HP], grads[HP], rden[HP];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+    for (int p = 0; p < HP; ++p)
+      pi_a[p] = f32x2{__builtin_nontemporal_load(row_a + l + 64 * p), __builtin_nontemporal_load(row_a + l + 64 * p + 32)};
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)(D - U); ++r)
+      if (r < n) request(r, r);  // rows 0 .. D-U-1 fly during the per-node set-up
+    // the edge-set probes of the same neighbours fly together with those rows (loads return in order: after them)
+    for (uint32_t q = l; q < n; q += 32) {
+      const uint32_t nb = s_nb[q];
+      if (set_has(a.set, make_edge(node, nb))) s_nb[q] = nb | 0x80000000u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      grads[p] = f32x2{0.0f, 0.0f};
+      const f32x2 den = pi_a[p] * phi_sum;
+      rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
+      node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
+      // sqrt(eps_t * phi_k) of the SGLD step, parked in the lane's noise slots (LDS: not live across the row loop)
+      const f32x2 ep = den * st.eps_t;
+      s_nz[64 * p] = sqrtf(ep.x);
+      s_nz[64 * p + 32] = sqrtf(ep.y);
+    }
+    // the lane's normals, while the first rows are on their way: stream v draws for its columns in ascending order
+    // (VL = 32: one stream, columns j = 0, 1, 2, ...; VL = 64: stream 0 even j = .x of every pair, stream 1 odd j = .y).
+    // One rolled loop: a single copy of the ziggurat code.
+    if (a.noise_on && on) {  // (an idle half's streams do not advance)
+#pragma unroll 1
+      for (int p = 0; p < HP; ++p) {
+        const float z0 = rng_normal(rs[0], &zig);
+        const float z1 = rng_normal(rs[NS - 1], &zig);
+        s_nz[64 * p] = s_nz[64 * p] * z0;
+        s_nz[64 * p + 32] = s_nz[64 * p + 32] * z1;
+      }
+    }
+
+    for (uint32_t q = 0; q < n; q += U) {  // n is a multiple of U (dispatch)
+      float* row[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) row[r] = ring + ((q + r) & (D - 1)) * SLOT;
+      // every LDS read of rows q-U .. q-1 has been consumed; their slots take rows q+D-U .. q+D-1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (q + (D - U) < n) {
+#pragma unroll
+        for (int r = 0; r < U; ++r) request(q + (D - U) + r, (q + (D - U) + r) & (D - 1));
+      }
+      {  // rows q .. q+U-1 landed; rows q+U .. min(q+D-1, n-1) may still be in flight (a multiple of U of them)
+        const uint32_t rem = n - U - q < (uint32_t)(D - U) ? n - U - q : (uint32_t)(D - U);
+        if (rem >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * PIECES) : "memory");
+        else if (rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PIECES) : "memory");
+        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      float ee[U], sg[U], lo[U], psum[U];
+      float part[U][NS];
+      f32x2 prr[U][HP];
+      bool fast[U], all_fast = true;
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        const bool y = (s_nb[q + r] >> 31) != 0;  // this half's flag
+        ee[r] = y ? EPS : 1.0f - EPS;
+        sg[r] = y ? 1.0f : -1.0f;  // e - pin (beta - EPS) == e + (-(pin (beta - EPS))): the negation is exact
+        lo[r] = 1.0f;
+#pragma unroll
+        for (int v = 0; v < NS; ++v) part[r][v] = 0.0f;
+      }
+      // pass 1 of all U rows (phi.cc:241-253): probs[], lane partials in ascending column order
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const f32x2 pin = f32x2{row[r][lds_col(2 * p)], row[r][lds_col(2 * p + 1)]};
+          const f32x2 tt = (pin * bf[p]) * sg[r] + ee[r];
+          const f32x2 pr = pi_a[p] * tt;
+          prr[r][p] = pr;
+          part[r][0] += pr.x;       // VL = 32: one chain over j = 2p, 2p + 1; VL = 64: work-item l takes the even j,
+          part[r][NS - 1] += pr.y;  // work-item l + 32 the odd ones
+          lo[r] = fminf(fminf(lo[r], fabsf(pr.x)), fabsf(pr.y));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        // VL = 64: aux[l] += aux[l + 32] is the tree's first level (sum.cc:23-29), inside the lane here
+        const float lane_sum = NS == 1 ? part[r][0] : part[r][0] + part[r][NS - 1];
+        psum[r] = tree32(lane_sum);  // phi.cc:254-257
+        fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
+        all_fast = all_fast && fast[r];
+      }
+      // pass 2 (phi.cc:259-263): grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum, rows in order
+      if (all_fast) {
+        float ps = phi_sum;
+        asm volatile("" : "+v"(ps));  // keeps pi_a * phi_sum from being hoisted into KPT more registers
+        f32x2 s2[U], r2[U];
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const float rc = exact_rcp(psum[r]);
+          s2[r] = f32x2{psum[r], psum[r]};
+          r2[r] = f32x2{rc, rc};
+        }
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 den = pi_a[p] * ps;
+          f32x2 v[U];
+#pragma unroll
+          for (int r = 0; r < U; ++r) v[r] = div_exact3(div_exact3(prr[r][p], s2[r], r2[r]), den, rden[p]);
+#pragma unroll
+          for (int r = 0; r < U; ++r) grads[p] += v[r] - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const float probs_sum = psum[r];
+          if (fast[r]) {
+            const float rps = exact_rcp(probs_sum);
+            const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+              f32x2 qv = div_exact3(prr[r][p], psum2, rps2);
+              qv = div_exact3(qv, pi_a[p] * phi_sum, rden[p]);
+              grads[p] += qv - inv_phi_sum;
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+              const f32x2 den = pi_a[p] * phi_sum;
+              float v0 = prr[r][p].x / probs_sum, v1 = prr[r][p].y / probs_sum;
+              v0 = v0 / den.x;
+              v1 = v1 / den.y;
+              grads[p] += f32x2{v0 - inv_phi_sum, v1 - inv_phi_sum};
+            }
+          }
+        }
+      }
+    }
+
+    // SGLD step, phi.cc:265-274
+    if (on) {
+      float* out = a.phi_vec + i * K;
+      const float half = st.eps_t / 2;
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        const f32x2 phi_k = pi_a[p] * phi_sum;
+        const f32x2 ng = grads[p] * a.Nn;
+        f32x2 in = a.alpha - phi_k;
+        in = in + ng;
+        const f32x2 drift = in * half;
+        const f32x2 aa = phi_k + drift;
+        const f32x2 s2 = aa + f32x2{s_nz[64 * p], s_nz[64 * p + 32]};  // sqrt(eps_t phi_k) * noise (noise off: * 1, phi.cc:673-677)
+        const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
+        __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + l + 64 * p);
+        __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + l + 64 * p + 32);
+      }
+    }
+  }
+  if (live && a.noise_on) {
+#pragma unroll
+    for (int v = 0; v < NS; ++v) a.seeds[(uint64_t)g * VL + l + 32 * v] = rs[v];
+  }
+}
+
+template <int KPT, int D, int U, int VL>
+int launch_phi_pair(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = (size_t)(D + 1) * 2 * 32 * KPT * sizeof(float) + 2 * sizeof(uint32_t) * a.n;
+  static const std::string name = ammsb_kname("update_phi_pair_kernel<%d, %d, %d, %d>", KPT, D, U, VL);
+  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
+  update_phi_pair_kernel<KPT, D, U, VL><<<(n_groups + 1) / 2, 64, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 template <int KPT, int D, int U, int VL = 64>
 int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
@@ -1300,6 +1573,27 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
   }();
+  // Short rows, two nodes per wave (update_phi_pair_kernel): K = 256 / 512 at wg 32 or 64, n a multiple of 2.
+  // Opt-in (AMMSB_PHI_PAIR=1; 2 / 3 pick other ring depths / rows per step): bit-identical, but SLOWER at C2 in same-box
+  // A/B runs -- 110 / 89 us (wg 64 / 32) against 70 / 79 us for the one-node-per-wave kernels, link steps 50 against
+  // 35 us.  A lone pair wave needs ~1.8 x the time of a lone one-node wave: what a wave's time is made of at K = 256 is
+  // the per-lane column work and its LDS round trips (twice as long with 8 columns per lane), not the tree / reciprocal
+  // the pairing shares (profiles/r03_c2_pair_ab.log).
+  static const int pair_form = [] {
+    const char* f = getenv("AMMSB_PHI_PAIR");
+    return f ? atoi(f) : 0;
+  }();
+  if (pair_form > 0 && !force_reg && !force_gen && (wg == 32 || wg == 64) && (p.K == 256 || p.K == 512) &&
+      pi->num_cols % 4 == 0 && a.n >= 2 && a.n % 2 == 0 && a.n * sizeof(uint32_t) <= 4096) {
+    if (p.K == 256) {
+      if (pair_form == 3 && a.n % 4 == 0)
+        return wg == 32 ? launch_phi_pair<8, 8, 4, 32>(ctx, a, n_groups, s) : launch_phi_pair<8, 8, 4, 64>(ctx, a, n_groups, s);
+      if (pair_form == 2)
+        return wg == 32 ? launch_phi_pair<8, 8, 2, 32>(ctx, a, n_groups, s) : launch_phi_pair<8, 8, 2, 64>(ctx, a, n_groups, s);
+      return wg == 32 ? launch_phi_pair<8, 4, 2, 32>(ctx, a, n_groups, s) : launch_phi_pair<8, 4, 2, 64>(ctx, a, n_groups, s);
+    }
+    return wg == 32 ? launch_phi_pair<16, 4, 2, 32>(ctx, a, n_groups, s) : launch_phi_pair<16, 4, 2, 64>(ctx, a, n_groups, s);
+  }
   // The reference's default work-group size (32, main.cc:61) on rows of 256 .. 2048 columns: 32 virtual lanes in the
   // one-wave-per-node LDS-streamed kernels (VLane<32>); K / 32 columns per work-item = 2 x the columns per physical lane
   if (wg == 32 && !force_reg && !force_gen && pi->num_cols % 4 == 0 && a.n * sizeof(uint32_t) <= 8192) {

@@ -135,3 +135,57 @@ def test_generic_forms_match_specialised_and_oracle(orc, tmp_path):
     out = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "phi ok" in out.stdout and "beta ok" in out.stdout and "ppx ok" in out.stdout
+
+
+PAIR_CHILD = r"""
+import sys
+import numpy as np
+sys.path[:0] = [%(root)r, %(tests)r]
+import torch
+import ammsb_pkg
+ammsb_pkg.load()
+from mcmc_ammsb_gpu_amd import ops as hip
+import oracle_lib as orc
+orc.build()
+from test_gpu_parity import Problem
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+for N, K, n, n_nodes, L in [(2048, 256, 32, 201, 64), (2048, 256, 32, 200, 32), (2048, 256, 6, 100, 64),
+                            (2048, 512, 32, 101, 64), (2048, 512, 8, 100, 32), (70000, 256, 4, 65535 + 700, 64)]:
+    for noise in (False, True):
+        pr = Problem(orc, hip, N, K, n, n_nodes, deg=4 if N > 10000 else 16)
+        upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L,
+                             phi_disable_noise=not noise)
+        seeds = orc.rng_init(n_nodes * L, 42, 43)
+        pi_h, phi_sum_h = pr.pi_h.copy(), pr.phi_sum_h.copy()
+        for step in (1, 2):
+            upd(pr.nodes, pr.nb, n_nodes)
+            pr.sync()
+            assert "pair_kernel" in pr.ctx.kernel_names()["update_phi"], pr.ctx.kernel_names()
+            want = orc.update_phi(pr.p_orc, pr.beta_h, pi_h.reshape(-1), phi_sum_h, pr.oset, pr.nodes_h,
+                                  pr.nb_h.reshape(-1), step, seeds, L, 1, noise)
+            got = upd.phi_vec.cpu().numpy()[:n_nodes]
+            assert np.array_equal(bits(got), bits(want)), ("phi_vec", N, K, n, L, noise, step)
+            assert np.array_equal(upd.rand.host(), seeds), ("streams", K, L)
+            orc.update_pi(pr.p_orc, pi_h.reshape(-1), phi_sum_h, want.reshape(-1), pr.nodes_h, L, 1)
+            if N > 10000:
+                break
+            assert np.array_equal(bits(pr.pi.host()), bits(pi_h)), ("pi", K, L)
+        pr.ctx.close()
+print("pair ok")
+"""
+
+
+def test_two_nodes_per_wave_update_phi(orc):
+    """update_phi_pair_kernel (opt-in, AMMSB_PHI_PAIR=1): each half of a wave owns a node; work-group sizes 32 and 64,
+    odd node counts (an idle half), more nodes than groups (a half with a second node)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no fallback path exists)")
+    env = dict(os.environ, AMMSB_PHI_PAIR="1")
+    script = PAIR_CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "pair ok" in out.stdout
