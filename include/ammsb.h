@@ -282,13 +282,21 @@ int ammsb_loop_destroy(ammsb_loop* loop);
 int ammsb_loop_run(ammsb_loop* loop, const ammsb_mb_choice* pending, const ammsb_mb_choice* next, uint32_t n_steps,
                    uint32_t first_step_count, uint32_t parity, void* stream);
 /* The two chains of an iteration (main: phi, pi, beta; sampler: the mini-batch two steps ahead) are ordered on the
- * device by polling kernels, not by stream events.  A wait that is not satisfied within 5 s gives up instead of
- * hanging the device; this call synchronises the loop's streams and returns how many did since the last call -- 0 in
- * every correct run, and callers treat anything else as an error (the steps since then used unfinished
- * mini-batches).  Tools that run one kernel at a time starve a polling kernel's producer:
- * AMMSB_LOOP_HANDSHAKE=event in the environment at ammsb_loop_create orders the chains with stream events instead
- * (the default when rocprofv3 --pmc's ROCPROF_COUNTER_COLLECTION is set; AMMSB_LOOP_HANDSHAKE=flag overrides). */
+ * device by polling kernels, not by stream events.  A wait that is not satisfied within 5 s GIVES UP instead of
+ * hanging the device, and everything behind it is skipped rather than run on a mini-batch that is not there: the
+ * model, the RNG streams and the sample buffers stay those of the last completed step.  This call synchronises the
+ * loop's streams; if a wait gave up since the last call it switches the loop to the stream-event hand-over for good,
+ * re-enqueues the steps that did not run (same kernels, same arguments, same order: the trajectory is the undisturbed
+ * one), waits for them and counts a fallback (ammsb_loop_status).  *wait_timeouts stays 0 unless that recovery itself
+ * failed; callers treat a non-zero value as an error.  At ammsb_loop_create the loop checks once whether its two
+ * streams can overlap at all (a kernel on one spins <= 20 ms for a flag a kernel on the other sets) and takes the
+ * event hand-over from the start if they cannot (one hardware queue, tools that run one kernel at a time);
+ * AMMSB_LOOP_HANDSHAKE=event|flag in the environment forces either form.  Runs of different loops are submitted one
+ * whole run at a time (a process-wide lock), so concurrent learners cannot interleave their polling kernels. */
 int ammsb_loop_check(ammsb_loop* loop, uint32_t* wait_timeouts);
+/* *event_handover: 1 if the loop orders its chains with stream events (from the start, or since a fallback);
+ * *fallbacks: runs that were finished on the event hand-over after a device-side wait gave up.  Either may be NULL. */
+int ammsb_loop_status(const ammsb_loop* loop, uint32_t* event_handover, uint32_t* fallbacks);
 /* (AMMSB_LOOP_TIMESTAMPS) device time in ns at which update_phi of steps first_step .. first_step + n_steps - 1
  * began, and at which the kernel after it (update_pi) began -- update_phi's duration plus one kernel boundary: a
  * slight over-estimate, never an under-estimate.  The last 8192 steps are kept.  Synchronises. */

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ammsb_loop_destroy": [_vp],
     "ammsb_loop_run": [_vp, _P(MbChoice), _P(MbChoice), _u32, _u32, _u32, _vp],
     "ammsb_loop_check": [_vp, _P(_u32)],
+    "ammsb_loop_status": [_vp, _P(_u32), _P(_u32)],
     "ammsb_loop_timestamps": [_vp, _u32, _u32, _P(C.c_double), _P(C.c_double)],
     "ammsb_loop_step_stamps": [_vp, _u32, _u32, _P(C.c_double)],
     "ammsb_wg_sum_f32": [_vp, _vp, _vp, _u32, _u32, _u32, _vp],

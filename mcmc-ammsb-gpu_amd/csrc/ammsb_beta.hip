@@ -66,6 +66,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   __shared__ float aux[Grp::AUX];
   const int l = Grp::lane();
   const BetaStep st = beta_step(a);
+  if (st.P == 0) return;  // (uniform) a skipped step
   beta_stamp<FUSE>(a);
   const uint32_t gs = blockIdx.x * Grp::PER_BLOCK + Grp::slot();  // partial-row slot
   const bool live = gs < st.P;
@@ -569,6 +570,7 @@ int launch_grads_lds(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials, uint32_t P, uint32_t cols,
                                                             float* out, const ammsb_step_desc* desc) {
   __shared__ float red[16][17];
+  if (ammsb_desc_skip(desc)) return;
   if (desc) P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)
   const uint32_t cl = threadIdx.x & 15, r = threadIdx.x >> 4;
   const uint32_t c = blockIdx.x * 16 + cl;
@@ -590,6 +592,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partials
 __global__ __launch_bounds__(256) void sum_partials8_kernel(const float* partials, uint32_t P, uint32_t cols,
                                                              float* out, const ammsb_step_desc* desc) {
   __shared__ float4 red[128][2];
+  if (ammsb_desc_skip(desc)) return;
   if (desc) P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)
   const uint32_t h = threadIdx.x & 1, r = threadIdx.x >> 1;
   const uint32_t c = blockIdx.x * 8 + 4 * h;
@@ -656,6 +659,11 @@ __device__ __forceinline__ void theta_step(uint32_t k, float g0, float g1, float
 // captured graph: hand the next two descriptors of the ring to the graph that runs next, advance the cursor
 __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv, const ammsb_step_desc* desc) {
   if (!adv.ring) return;
+  if (ammsb_desc_skip(desc)) {  // this step was skipped (a wait gave up earlier): so is the next one; count nothing
+    adv.cur_out->n_nodes = 0;
+    adv.cur_out->n_edges = 0;
+    return;
+  }
   unsigned long long* stamp = adv.stamps ? adv.stamps + AMMSB_STAMP_SLOTS * (desc->step % AMMSB_STAMP_CAP) : nullptr;
   const uint32_t c = *adv.cursor;
   *adv.cur_out = adv.ring[c + 1];
@@ -670,8 +678,13 @@ __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv, cons
     if (adv.avail) {  // hold this kernel (one lane of one block) until the next step's mini-batch has been sampled
       const unsigned long long t0 = wall_clock64();
       while ((int)(__hip_atomic_load(adv.avail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - done) < 1) {
-        if (wall_clock64() - t0 > adv.max_ticks) {
-          atomicAdd(adv.timeouts, 1u);
+        // gives up after max_ticks, or at once when another wait already has (the sampling chain skips from then on):
+        // the next step must not run on a mini-batch that is not there -- it gets a skip descriptor, and hands it on
+        const bool gave_up = wall_clock64() - t0 > adv.max_ticks;
+        if (gave_up || __hip_atomic_load(adv.timeouts, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (gave_up) atomicAdd(adv.timeouts, 1u);
+          adv.cur_out->n_nodes = 0;
+          adv.cur_out->n_edges = 0;
           break;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -695,6 +708,10 @@ __global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* b
   if (desc) {  // captured graph: this step's scalars
     eps_t = desc->eps_t;
     scale = desc->scale;
+    if (ammsb_desc_skip(desc)) {  // (uniform) a skipped step: theta and its streams stay as they are
+      if (k == 0) step_advance(adv, desc);
+      return;
+    }
     note_stamp(adv.stamps, desc, AMMSB_STAMP_THETA);
     if (k == 0) step_advance(adv, desc);
   }
@@ -712,6 +729,10 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
                                                                 const ammsb_step_advance adv) {
   __shared__ float4 red[128][2];
   __shared__ ZigTables zig;
+  if (ammsb_desc_skip(desc)) {  // (uniform) a skipped step: gradient, theta, beta and the streams stay as they are
+    if (blockIdx.x == 0 && threadIdx.x == 64) step_advance(adv, desc);
+    return;
+  }
   zig_load(&zig);
   note_stamp(adv.stamps, desc, AMMSB_STAMP_THETA);
   P = desc->n_edges < P ? desc->n_edges : P;  // the gradient kernel's slot count (beta_step)

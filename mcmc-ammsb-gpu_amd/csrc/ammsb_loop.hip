@@ -38,8 +38,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <new>
 #include <thread>
+#include <vector>
 
 namespace {
 
@@ -47,11 +49,17 @@ constexpr uint32_t CHUNK = 1024;                 // steps per descriptor upload
 constexpr uint32_t STAMP_CAP = AMMSB_STAMP_CAP;  // steps whose update_phi timestamps are kept
 constexpr int NBUF = 3;                          // sample buffer sets: the caller's two + one of the loop's own
 
+// (timeouts: non-null with the device-side hand-over; once a wait has given up, the steps of later chunks and runs are
+// skipped like the rest -- the prime kernel must not hand them a live descriptor)
 __global__ void loop_prime_kernel(const ammsb_step_desc* ring, uint32_t* cursor, ammsb_step_desc* cur,
-                                  ammsb_step_desc* nxt) {
+                                  ammsb_step_desc* nxt, const uint32_t* timeouts) {
   *cur = ring[0];  // the step that runs next
   *nxt = ring[2];  // the mini-batch its sampler chain produces (two steps ahead)
   *cursor = 0;
+  if (timeouts && *timeouts != 0u) {
+    cur->n_nodes = 0;
+    cur->n_edges = 0;
+  }
 }
 
 // ---- device-side hand-shake.  hs[0] = main chains completed, hs[1] = mini-batches available (both count over the
@@ -60,24 +68,75 @@ __global__ void loop_prime_kernel(const ammsb_step_desc* ring, uint32_t* cursor,
 // waiting stream itself.
 constexpr int HS_MAIN = 0, HS_AVAIL = 1, HS_TIMEOUTS = 2;
 
+// A wait that is not satisfied within max_ticks GIVES UP: it counts itself in *timeouts, and from then on the run is
+// "poisoned" -- every later wait gives up at once, and what a given-up wait guards is skipped instead of run on data
+// that is not there (skip descriptors, ammsb_step.h), so the state stays that of the last completed step and the host
+// can resume from it (ammsb_loop_check).  `src` / `dst` (sampler chain): the chain's kernels read their descriptor from
+// the private copy `dst`, which this kernel fills -- with *src when the wait is satisfied, with a skip when it gave up.
+// fail_at (test hook, AMMSB_LOOP_TEST_FAIL_AT): the wait whose own counter *b equals fail_at - 1 gives up at once.
 __global__ void loop_wait_kernel(const uint32_t* a, const uint32_t* b, int min_diff, uint32_t* timeouts,
-                                 unsigned long long max_ticks) {
+                                 unsigned long long max_ticks, const ammsb_step_desc* src, ammsb_step_desc* dst,
+                                 uint32_t fail_at) {
   const uint32_t have = *b;
   const unsigned long long t0 = wall_clock64();
+  bool ok = false;
   for (;;) {
+    if (__hip_atomic_load(timeouts, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // poisoned
+    if (fail_at != 0u && have + 1u == fail_at) {
+      atomicAdd(timeouts, 1u);
+      break;
+    }
     const uint32_t v = __hip_atomic_load(a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if ((int)(v - have) >= min_diff) return;
+    if ((int)(v - have) >= min_diff) {
+      ok = true;
+      break;
+    }
     if (wall_clock64() - t0 > max_ticks) {  // a bug or a kernel-serialising tool: never hang the device
       atomicAdd(timeouts, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (dst) {
+    if (ok) {
+      *dst = *src;
+    } else {
+      ammsb_step_desc skip = *src;
+      skip.n_nodes = 0;
+      skip.n_edges = 0;
+      skip.n_cand = 0;
+      *dst = skip;
+    }
+  }
+}
+
+// end of a sampler chain: one more mini-batch available (not when the chain was skipped)
+__global__ void loop_bump_kernel(uint32_t* counter, const ammsb_step_desc* desc) {
+  if (ammsb_desc_skip(desc)) return;
+  __hip_atomic_store(counter, *counter + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the run's epilogue copy of the pending mini-batch into the caller's buffer set -- unless the run is poisoned (the
+// source may then not have been sampled, and the destination may hold a mini-batch the resumed run still needs)
+__global__ void loop_copy_kernel(uint4* dst, const uint4* src, size_t n16, const uint32_t* timeouts) {
+  if (timeouts && *timeouts != 0u) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+// create-time probe: can a kernel on one stream run while a kernel on the other is spinning?
+__global__ void loop_probe_wait_kernel(const uint32_t* flag, uint32_t* saw, unsigned long long max_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 <= max_ticks) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      *saw = 1u;
       return;
     }
     __builtin_amdgcn_s_sleep(8);
   }
+  *saw = 0u;
 }
-
-__global__ void loop_bump_kernel(uint32_t* counter) {
-  __hip_atomic_store(counter, *counter + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
+__global__ void loop_probe_set_kernel(uint32_t* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Stage {
   ammsb_step_desc* ring;  // pinned host staging, [CHUNK + 4]
@@ -111,7 +170,20 @@ struct ammsb_loop {
   ammsb_step_desc* d_nxt[NBUF];  // descriptor of the mini-batch being sampled into buffer set b (a sampler chain may
                                  // still be reading it two main chains later: one per buffer set, not per parity)
   uint32_t* d_hs;                // hand-shake counters (HS_*)
-  bool use_events;               // AMMSB_LOOP_HANDSHAKE=event: also order the chains with stream events
+  ammsb_step_desc* d_samp[NBUF]; // the sampler chain's private copy of its descriptor (filled by its wait kernel)
+  bool use_events;               // the chains are ordered with stream events (no polling kernels)
+  bool direct_only;              // the captured graphs are stale (they poll; the loop fell back to events): launch directly
+  uint32_t fallbacks;            // runs that were finished on the event hand-over after a device-side wait gave up
+  uint32_t test_fail_at;         // AMMSB_LOOP_TEST_FAIL_AT: the sampler chain of this lifetime mini-batch fails its wait
+  struct Run {                   // what was enqueued since the last ammsb_loop_check (to resume from, if need be)
+    ammsb_mb_choice pending;
+    std::vector<ammsb_mb_choice> next;
+    uint32_t n_steps, first_step_count, parity;
+    hipStream_t stream;
+    uint64_t main_start;         // lifetime main chains before this run
+  };
+  std::vector<Run>* runs;
+  uint64_t main_total;           // lifetime main chains enqueued
   unsigned long long wait_ticks; // a wait gives up after this many wall-clock ticks
   unsigned long long* d_stamps;  // [STAMP_CAP][AMMSB_STAMP_SLOTS] or null
   Stage stage[2];
@@ -127,7 +199,7 @@ struct ammsb_loop {
                        // replays the captured graphs from two threads instead
   bool host_prof;  // AMMSB_LOOP_HOSTPROF=1: time the two graph launches of a step on the host, print at destroy
   double t_side_us, t_main_us, t_run_us, t_pro_us, t_epi_us;
-  uint64_t runs;
+  uint64_t runs_done;
 };
 
 namespace {
@@ -154,10 +226,13 @@ int record_sampler(ammsb_loop* lp, int nl, int b, int sp, const ammsb_step_desc*
   ammsb_ctx* ctx = lp->ctx;
   const SampleBuf& o = lp->buf[b];
   const uint32_t m = c.mini_batch;
-  // mini-batch J = hs[AVAIL] goes into the buffer set step J - 3 read: wait for main chains 0 .. J - 3
+  // mini-batch J = hs[AVAIL] goes into the buffer set step J - 3 read: wait for main chains 0 .. J - 3.  The chain's
+  // kernels then read the wait kernel's private copy of the descriptor (a skip if the wait gave up).
   if (!lp->use_events) {
-    loop_wait_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_MAIN, lp->d_hs + HS_AVAIL, -2, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks);
+    loop_wait_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_MAIN, lp->d_hs + HS_AVAIL, -2, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks,
+                                      desc, lp->d_samp[b], lp->test_fail_at);
     LOOP_HIP(lp, hipGetLastError());
+    desc = lp->d_samp[b];
   }
   if (nl)
     LOOP_RC(ammsb_minibatch_link_d(ctx, c.csr_offsets, c.csr_targets, lp->link_edges_cap, o.edges, o.nodes, desc, st));
@@ -168,7 +243,7 @@ int record_sampler(ammsb_loop* lp, int nl, int b, int sp, const ammsb_step_desc*
   LOOP_RC(ammsb_sample_neighbors_d(ctx, c.nbr_seeds[sp], o.nodes, nl ? lp->link_nodes_cap : m + 1, c.nbr_wg, o.nbr_table,
                                    o.neighbors, desc, st));
   if (!lp->use_events) {
-    loop_bump_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_AVAIL);
+    loop_bump_kernel<<<1, 1, 0, st>>>(lp->d_hs + HS_AVAIL, desc);
     LOOP_HIP(lp, hipGetLastError());
   }
   return AMMSB_OK;
@@ -239,7 +314,7 @@ void destroy(ammsb_loop* lp) {
             "ammsb_loop host profile: %llu steps, hipGraphLaunch sampler %.2f us, main %.2f us per step; %llu runs: %.1f us "
             "each (prologue %.1f, epilogue %.1f)\n",
             (unsigned long long)lp->graphs_launched, lp->t_side_us / lp->graphs_launched, lp->t_main_us / lp->graphs_launched,
-            (unsigned long long)lp->runs, lp->t_run_us / lp->runs, lp->t_pro_us / lp->runs, lp->t_epi_us / lp->runs);
+            (unsigned long long)lp->runs_done, lp->t_run_us / lp->runs_done, lp->t_pro_us / lp->runs_done, lp->t_epi_us / lp->runs_done);
   if (lp->main) (void)hipStreamSynchronize(lp->main);
   if (lp->side) (void)hipStreamSynchronize(lp->side);
   for (int a = 0; a < 2; ++a)
@@ -261,6 +336,7 @@ void destroy(ammsb_loop* lp) {
   if (lp->own_mem) (void)hipFree(lp->own_mem);
   if (lp->side) (void)hipStreamDestroy(lp->side);
   if (lp->main) (void)hipStreamDestroy(lp->main);
+  delete lp->runs;
   delete lp;
 }
 
@@ -364,8 +440,13 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     lp->buf[2].neighbors = reinterpret_cast<uint32_t*>(p + e_b + n_b);
     lp->buf[2].nbr_table = reinterpret_cast<uint32_t*>(p + e_b + n_b + p_b);
   }
-  // one device allocation: ring [CHUNK + 4], cur[2], nxt[3], cursor
-  const size_t n_desc = CHUNK + 4 + 5;
+  lp->runs = new (std::nothrow) std::vector<ammsb_loop::Run>();
+  if (!lp->runs) {
+    destroy(lp);
+    return AMMSB_ENOMEM;
+  }
+  // one device allocation: ring [CHUNK + 4], cur[2], nxt[3], samp[3], cursor
+  const size_t n_desc = CHUNK + 4 + 8;
   CREATE_HIP(hipMalloc(&lp->d_ring, sizeof(ammsb_step_desc) * n_desc + 64));
   CREATE_HIP(hipMemset(lp->d_ring, 0, sizeof(ammsb_step_desc) * n_desc + 64));
   lp->d_cur[0] = lp->d_ring + CHUNK + 4;
@@ -373,6 +454,7 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
   lp->d_nxt[0] = lp->d_ring + CHUNK + 6;
   lp->d_nxt[1] = lp->d_ring + CHUNK + 7;
   lp->d_nxt[2] = lp->d_ring + CHUNK + 8;
+  for (int b = 0; b < NBUF; ++b) lp->d_samp[b] = lp->d_ring + CHUNK + 9 + b;
   lp->d_cursor = reinterpret_cast<uint32_t*>(lp->d_ring + n_desc);
   {
     CREATE_HIP(hipMalloc(&lp->d_hs, 64));
@@ -388,6 +470,25 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     const bool serialising_tool = truthy(pmc) || truthy(getenv("AMD_SERIALIZE_KERNEL")) || truthy(getenv("HIP_LAUNCH_BLOCKING")) ||
                                   truthy(getenv("CUDA_LAUNCH_BLOCKING"));
     lp->use_events = mode ? strcmp(mode, "event") == 0 : serialising_tool;
+    int khz0 = 100000;
+    CREATE_HIP(hipDeviceGetAttribute(&khz0, hipDeviceAttributeWallClockRate, ctx->device));
+    if (!lp->use_events && !(mode && strcmp(mode, "flag") == 0)) {
+      // Can the two streams overlap at all?  A kernel on `main` spins (<= 20 ms) for a flag that a kernel on `side` sets.
+      // If it never sees it -- one hardware queue for both streams (GPU_MAX_HW_QUEUES=1), a tool that runs one kernel
+      // at a time -- device-side polling would only ever time out: order the chains with stream events instead.
+      uint32_t* probe = lp->d_hs + 8;  // [8] flag, [9] saw
+      CREATE_HIP(hipMemset(probe, 0, 2 * sizeof(uint32_t)));
+      loop_probe_wait_kernel<<<1, 1, 0, lp->main>>>(probe, probe + 1, 20ull * (unsigned long long)(khz0 > 0 ? khz0 : 100000));
+      CREATE_HIP(hipGetLastError());
+      loop_probe_set_kernel<<<1, 1, 0, lp->side>>>(probe);
+      CREATE_HIP(hipGetLastError());
+      CREATE_HIP(hipStreamSynchronize(lp->main));
+      CREATE_HIP(hipStreamSynchronize(lp->side));
+      uint32_t saw = 0;
+      CREATE_HIP(hipMemcpy(&saw, probe + 1, sizeof saw, hipMemcpyDeviceToHost));
+      if (!saw) lp->use_events = true;
+    }
+    if (const char* f = getenv("AMMSB_LOOP_TEST_FAIL_AT")) lp->test_fail_at = (uint32_t)atoi(f);
     lp->host_prof = getenv("AMMSB_LOOP_HOSTPROF") != nullptr;
     const char* lm = getenv("AMMSB_LOOP_LAUNCH");
     lp->serial_launch = lm && strcmp(lm, "serial") == 0;
@@ -395,6 +496,8 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     int khz = 100000;
     CREATE_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
     lp->wait_ticks = 5000ull * (unsigned long long)(khz > 0 ? khz : 100000);  // 5 s
+    if (const char* w = getenv("AMMSB_LOOP_WAIT_MS"))  // (tests: a short give-up time)
+      lp->wait_ticks = (unsigned long long)atoi(w) * (unsigned long long)(khz > 0 ? khz : 100000);
   }
   for (Stage& st : lp->stage) {
     CREATE_HIP(hipHostMalloc(&st.ring, sizeof(ammsb_step_desc) * (CHUNK + 4), hipHostMallocDefault));
@@ -426,16 +529,19 @@ extern "C" int ammsb_loop_destroy(ammsb_loop* lp) {
   return AMMSB_OK;
 }
 
-extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, const ammsb_mb_choice* next,
-                              uint32_t n_steps, uint32_t first_step_count, uint32_t parity, void* stream) {
-  if (!lp) return AMMSB_EINVAL;
+// Process-wide: a run's chains are submitted as one unit.  Two loops driven from two host threads could otherwise
+// interleave their submissions on shared hardware queues so that each one's polling kernel sits ahead of the other's
+// producer (a cycle across the queues: both would wait until they give up).  With whole runs submitted one after the
+// other, every polling kernel's producer is ahead of it in submission order, whatever the stream-to-queue map is.
+static std::mutex g_submit_mutex;
+
+namespace {
+
+// Enqueues steps [done0, n_steps) of a run whose mini-batches [0, avail0) are already available (avail0 = 1: only the
+// pending one, the normal entry; more after a resumed run, whose earlier sampler chains had completed).
+int submit(ammsb_loop* lp, const ammsb_mb_choice* pending, const ammsb_mb_choice* next, uint32_t n_steps,
+           uint32_t first_step_count, uint32_t parity, hipStream_t s, uint32_t done0, uint32_t avail0) {
   ammsb_ctx* ctx = lp->ctx;
-  AMMSB_CHECK_ARG(ctx, pending && (next || n_steps == 0), "null argument");
-  AMMSB_CHECK_ARG(ctx, parity < 2 && first_step_count >= 1, "bad parity / step count");
-  if (n_steps == 0) return AMMSB_OK;
-  LOOP_RC(check_choice(lp, *pending));
-  for (uint32_t i = 0; i < n_steps; ++i) LOOP_RC(check_choice(lp, next[i]));
-  hipStream_t s = as_stream(stream);
   const uint32_t p0 = parity;
   const bool ev = lp->use_events;
   using clk = std::chrono::steady_clock;
@@ -446,7 +552,7 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
   auto choice = [&](uint32_t j) -> const ammsb_mb_choice& { return j == 0 ? *pending : next[j - 1]; };
   LOOP_HIP(lp, hipEventRecord(lp->ev_in, s));
   LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_in, 0));
-  uint32_t done = 0;
+  uint32_t done = done0;
   while (done < n_steps) {
     const uint32_t cnt = n_steps - done < CHUNK ? n_steps - done : CHUNK;
     const clk::time_point t_pro = clk::now();
@@ -463,18 +569,25 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
     LOOP_HIP(lp, hipEventRecord(st.done, lp->main));
     st.used = true;
     const int dp0 = (int)((p0 + done) & 1u);
-    loop_prime_kernel<<<1, 1, 0, lp->main>>>(lp->d_ring, lp->d_cursor, lp->d_cur[dp0], lp->d_nxt[(p0 + done + 2) % NBUF]);
+    loop_prime_kernel<<<1, 1, 0, lp->main>>>(lp->d_ring, lp->d_cursor, lp->d_cur[dp0], lp->d_nxt[(p0 + done + 2) % NBUF],
+                                             ev ? nullptr : lp->d_hs + HS_TIMEOUTS);
     LOOP_HIP(lp, hipGetLastError());
     LOOP_HIP(lp, hipEventRecord(lp->ev_prime, lp->main));
-    if (done == 0) {
-      // ramp-up: mini-batch 1 is sampled before step 0 starts (eagerly, straight from its ring entry); from then on
-      // the sampler chain of step i produces mini-batch i + 2
-      LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
-      LOOP_RC(record_sampler(lp, choice(1).link ? 1 : 0, (int)((p0 + 1) % NBUF), (int)((p0 + 1) & 1u), lp->d_ring + 1, lp->side));
-      if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_first, lp->side));
+    if (done == done0) {
+      // ramp-up: the mini-batches of steps done0 and done0 + 1 that are not there yet are sampled before the first
+      // step starts (eagerly, straight from their ring entries); from then on the sampler chain of step i produces
+      // mini-batch i + 2.  Normal entry (done0 = 0, the pending mini-batch available): mini-batch 1.
+      const uint32_t hi = done0 + 2 < n_steps + 1 ? done0 + 2 : n_steps + 1;
+      for (uint32_t j = avail0 > done0 ? avail0 : done0; j < hi; ++j) {
+        if (j == 0) continue;  // (the pending mini-batch is the caller's)
+        LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
+        LOOP_RC(record_sampler(lp, choice(j).link ? 1 : 0, (int)((p0 + j) % NBUF), (int)((p0 + j) & 1u),
+                               lp->d_ring + (j - done0), lp->side));
+        if (ev) LOOP_HIP(lp, hipEventRecord(j == 1 ? lp->ev_first : lp->ev_samp[(j - 2) % NBUF], lp->side));
+      }
     }
     lp->t_pro_us += us_since(t_pro);
-    bool threaded = !ev && cnt >= 32 && !lp->serial_launch;
+    bool threaded = !ev && cnt >= 32 && !lp->serial_launch && avail0 <= 1;
     if (threaded) {
       // With the device-side hand-shake nothing on the host orders the two chains any more: the sampler graphs of
       // the chunk are launched from a second thread while this one launches the main graphs (a launch costs
@@ -534,7 +647,10 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t gi = done + i;  // step index within this call
       const int dp = (int)((p0 + gi) & 1u);
-      if (gi + 2 <= n_steps) {  // the call ends with exactly ONE pending mini-batch (n_steps), like the eager loop
+      // mini-batch gi + 2: sampled now, unless an earlier (interrupted) submission of this run already produced it.
+      // The call ends with exactly ONE pending mini-batch (n_steps), like the eager loop.
+      const bool sample = gi + 2 <= n_steps && gi + 2 >= avail0;
+      if (sample) {
         // reads the descriptor the previous step's last kernel (or the prime kernel) handed over, overwrites the
         // buffer set step gi - 1 read
         // (the chain's own wait kernel holds it until main(gi - 1) is done; the first one of a chunk also needs
@@ -542,15 +658,22 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
         if (i == 0) LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
         else if (ev) LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_main[(gi - 1) % NBUF], 0));
         const auto t0 = lp->host_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        LOOP_HIP(lp, hipGraphLaunch(lp->exec_samp[choice(gi + 2).link ? 1 : 0][(p0 + gi + 2) % NBUF][dp], lp->side));
+        const int nl = choice(gi + 2).link ? 1 : 0, b = (int)((p0 + gi + 2) % NBUF);
+        if (lp->direct_only) LOOP_RC(record_sampler(lp, nl, b, dp, lp->d_nxt[b], lp->side));
+        else LOOP_HIP(lp, hipGraphLaunch(lp->exec_samp[nl][b][dp], lp->side));
         if (lp->host_prof) lp->t_side_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_samp[gi % NBUF], lp->side));
       }
-      // main chain of step gi: its mini-batch was sampled during step gi - 2 (gi = 1: by the ramp-up above)
-      if (ev && gi == 1) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_first, 0));
-      if (ev && gi >= 2) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(gi - 2) % NBUF], 0));
+      // main chain of step gi: its mini-batch was sampled during step gi - 2 (gi = 1: by the ramp-up above), or was
+      // already there when this submission began (gi < avail0)
+      if (ev && gi >= avail0) {
+        if (gi == 1) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_first, 0));
+        else LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_samp[(gi - 2) % NBUF], 0));
+      }
       const auto t1 = lp->host_prof ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-      LOOP_HIP(lp, hipGraphLaunch(lp->exec_main[choice(gi).link ? 1 : 0][(p0 + gi) % NBUF][dp], lp->main));
+      const int cl = choice(gi).link ? 1 : 0, bm = (int)((p0 + gi) % NBUF);
+      if (lp->direct_only) LOOP_RC(record_main(lp, cl, bm, dp, lp->main));
+      else LOOP_HIP(lp, hipGraphLaunch(lp->exec_main[cl][bm][dp], lp->main));
       if (lp->host_prof) lp->t_main_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
       if (ev) LOOP_HIP(lp, hipEventRecord(lp->ev_main[gi % NBUF], lp->main));
     }
@@ -559,9 +682,10 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
   }
   const clk::time_point t_epi = clk::now();
   // the pending mini-batch (n_steps): wait for its sampler, then move it into the caller's Sample[(p0 + n) % 2]
-  if (ev) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, n_steps == 1 ? lp->ev_first : lp->ev_samp[(n_steps - 2) % NBUF], 0));
+  if (ev && n_steps >= avail0) LOOP_HIP(lp, hipStreamWaitEvent(lp->main, n_steps == 1 ? lp->ev_first : lp->ev_samp[(n_steps - 2) % NBUF], 0));
   if (!ev) {
-    loop_wait_kernel<<<1, 1, 0, lp->main>>>(lp->d_hs + HS_AVAIL, lp->d_hs + HS_MAIN, 1, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks);
+    loop_wait_kernel<<<1, 1, 0, lp->main>>>(lp->d_hs + HS_AVAIL, lp->d_hs + HS_MAIN, 1, lp->d_hs + HS_TIMEOUTS, lp->wait_ticks,
+                                            nullptr, nullptr, 0u);
     LOOP_HIP(lp, hipGetLastError());
   }
   const uint32_t from = (p0 + n_steps) % NBUF, to = (p0 + n_steps) & 1u;
@@ -569,34 +693,120 @@ extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, co
     const ammsb_mb_choice& ch = choice(n_steps);
     const size_t ne = ch.link ? ch.n : lp->c.mini_batch, nv = ne + 1;
     const SampleBuf &a = lp->buf[from], &b = lp->buf[to];
-    LOOP_HIP(lp, hipMemcpyAsync(b.edges, a.edges, sizeof(uint64_t) * ne, hipMemcpyDeviceToDevice, lp->main));
-    LOOP_HIP(lp, hipMemcpyAsync(b.nodes, a.nodes, sizeof(uint32_t) * nv, hipMemcpyDeviceToDevice, lp->main));
-    LOOP_HIP(lp, hipMemcpyAsync(b.neighbors, a.neighbors, sizeof(uint32_t) * nv * lp->n_nbr, hipMemcpyDeviceToDevice, lp->main));
-    LOOP_HIP(lp, hipMemcpyAsync(b.nbr_table, a.nbr_table, sizeof(uint32_t) * nv * 2 * lp->n_nbr, hipMemcpyDeviceToDevice, lp->main));
+    // (kernels, not copy commands: a poisoned run must leave the destination alone -- see loop_copy_kernel; the
+    // buffers are whole allocations, so rounding the sizes up to 16 bytes stays inside them)
+    const uint32_t* poison = ev ? nullptr : lp->d_hs + HS_TIMEOUTS;
+    auto copy = [&](void* dst, const void* src, size_t bytes) {
+      const size_t n16 = (bytes + 15) / 16;
+      const unsigned blocks = (unsigned)(n16 / 256 + 1 < 1024 ? n16 / 256 + 1 : 1024);
+      loop_copy_kernel<<<blocks, 256, 0, lp->main>>>(static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16, poison);
+    };
+    copy(b.edges, a.edges, sizeof(uint64_t) * ne);
+    copy(b.nodes, a.nodes, sizeof(uint32_t) * nv);
+    copy(b.neighbors, a.neighbors, sizeof(uint32_t) * nv * lp->n_nbr);
+    copy(b.nbr_table, a.nbr_table, sizeof(uint32_t) * nv * 2 * lp->n_nbr);
+    LOOP_HIP(lp, hipGetLastError());
   }
   LOOP_HIP(lp, hipEventRecord(lp->ev_out, lp->main));
   LOOP_HIP(lp, hipStreamWaitEvent(s, lp->ev_out, 0));
   lp->t_epi_us += us_since(t_epi);
   lp->t_run_us += us_since(t_run);
-  lp->runs += 1;
+  lp->runs_done += 1;
   return AMMSB_OK;
 }
 
-// Synchronises the loop's streams and reports how many device-side waits gave up since the last call (0 in any
-// correct run; non-zero means the iterations since then ran on mini-batches that were not ready).
+}  // namespace
+
+extern "C" int ammsb_loop_run(ammsb_loop* lp, const ammsb_mb_choice* pending, const ammsb_mb_choice* next,
+                              uint32_t n_steps, uint32_t first_step_count, uint32_t parity, void* stream) {
+  if (!lp) return AMMSB_EINVAL;
+  ammsb_ctx* ctx = lp->ctx;
+  AMMSB_CHECK_ARG(ctx, pending && (next || n_steps == 0), "null argument");
+  AMMSB_CHECK_ARG(ctx, parity < 2 && first_step_count >= 1, "bad parity / step count");
+  if (n_steps == 0) return AMMSB_OK;
+  LOOP_RC(check_choice(lp, *pending));
+  for (uint32_t i = 0; i < n_steps; ++i) LOOP_RC(check_choice(lp, next[i]));
+  std::lock_guard<std::mutex> guard(g_submit_mutex);
+  if (!lp->use_events) {  // what a resumption would need (ammsb_loop_check)
+    try {
+      ammsb_loop::Run r;
+      r.pending = *pending;
+      r.next.assign(next, next + n_steps);
+      r.n_steps = n_steps;
+      r.first_step_count = first_step_count;
+      r.parity = parity;
+      r.stream = as_stream(stream);
+      r.main_start = lp->main_total;
+      lp->runs->push_back(std::move(r));
+    } catch (...) {
+      return AMMSB_ENOMEM;
+    }
+  }
+  lp->main_total += n_steps;
+  return submit(lp, pending, next, n_steps, first_step_count, parity, as_stream(stream), 0u, 1u);
+}
+
+// Synchronises the loop's streams.  If a device-side wait gave up since the last call, the kernels after it were
+// skipped (ammsb_step.h): the model, the streams and the sample buffers are those of the last completed step.  The
+// loop then switches to the stream-event hand-over for good, re-enqueues the steps that did not run -- same kernels,
+// same arguments, same order, so the trajectory is the one an undisturbed run has -- waits for them, and reports the
+// fallback through ammsb_loop_status.  *wait_timeouts is the number of waits that gave up WITHOUT a successful
+// resumption: 0 unless the recovery itself failed (callers treat that as an error).
 extern "C" int ammsb_loop_check(ammsb_loop* lp, uint32_t* wait_timeouts) {
   if (!lp) return AMMSB_EINVAL;
   ammsb_ctx* ctx = lp->ctx;
   AMMSB_CHECK_ARG(ctx, wait_timeouts, "null argument");
+  std::lock_guard<std::mutex> guard(g_submit_mutex);
   LOOP_HIP(lp, hipStreamSynchronize(lp->side));
   LOOP_HIP(lp, hipStreamSynchronize(lp->main));
   uint32_t hs[3] = {0, 0, 0};
   LOOP_HIP(lp, hipMemcpy(hs, lp->d_hs, sizeof hs, hipMemcpyDeviceToHost));
-  *wait_timeouts = hs[HS_TIMEOUTS];
-  if (hs[HS_TIMEOUTS]) {
-    const uint32_t fix[3] = {hs[HS_MAIN], hs[HS_MAIN] + 1u, 0u};  // back to a consistent boundary state
-    LOOP_HIP(lp, hipMemcpy(lp->d_hs, fix, sizeof fix, hipMemcpyHostToDevice));
+  *wait_timeouts = 0;
+  if (!hs[HS_TIMEOUTS]) {
+    lp->runs->clear();
+    return AMMSB_OK;
   }
+  // main chains completed over the loop's lifetime (the counter wraps at 2^32: take it relative to the total)
+  const uint64_t done_total = lp->main_total - (uint64_t)(uint32_t)((uint32_t)lp->main_total - hs[HS_MAIN]);
+  const uint32_t avail_ahead = hs[HS_AVAIL] - hs[HS_MAIN];  // mini-batches sampled and not yet consumed (1 .. 3)
+  lp->use_events = true;
+  lp->direct_only = true;
+  lp->eager_launch = false;
+  lp->fallbacks += 1;
+  const uint32_t clear = 0;
+  LOOP_HIP(lp, hipMemcpy(lp->d_hs + HS_TIMEOUTS, &clear, sizeof clear, hipMemcpyHostToDevice));
+  std::vector<ammsb_loop::Run> runs;
+  runs.swap(*lp->runs);
+  bool resumed = false;
+  for (const ammsb_loop::Run& r : runs) {
+    if (r.main_start + r.n_steps <= done_total && !resumed) continue;  // completed before the wait gave up
+    uint32_t done0 = 0, avail0 = 1;
+    if (!resumed) {
+      done0 = (uint32_t)(done_total - r.main_start);
+      avail0 = done0 + (avail_ahead <= 3 ? avail_ahead : 0);  // (0 ahead: the give-up was the poll for this very step's batch)
+      if (avail0 == 0) avail0 = 1;                            // the run's pending mini-batch is always there
+      resumed = true;
+    }
+    const int rc = submit(lp, &r.pending, r.next.data(), r.n_steps, r.first_step_count, r.parity, r.stream, done0, avail0);
+    if (rc != AMMSB_OK) {
+      *wait_timeouts = hs[HS_TIMEOUTS];
+      return rc;
+    }
+  }
+  LOOP_HIP(lp, hipStreamSynchronize(lp->side));
+  LOOP_HIP(lp, hipStreamSynchronize(lp->main));
+  // the counters are not maintained by the event hand-over: leave them at a consistent boundary state
+  const uint32_t fix[3] = {(uint32_t)lp->main_total, (uint32_t)lp->main_total + 1u, 0u};
+  LOOP_HIP(lp, hipMemcpy(lp->d_hs, fix, sizeof fix, hipMemcpyHostToDevice));
+  return AMMSB_OK;
+}
+
+// how the loop's two chains are ordered (0 = device-side polling, 1 = stream events) and how many times a run had to
+// be finished on the event hand-over after a device-side wait gave up
+extern "C" int ammsb_loop_status(const ammsb_loop* lp, uint32_t* event_handover, uint32_t* fallbacks) {
+  if (!lp) return AMMSB_EINVAL;
+  if (event_handover) *event_handover = lp->use_events ? 1u : 0u;
+  if (fallbacks) *fallbacks = lp->fallbacks;
   return AMMSB_OK;
 }
 

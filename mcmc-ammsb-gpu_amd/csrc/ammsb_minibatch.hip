@@ -146,6 +146,7 @@ __global__ __launch_bounds__(MB_BLOCK) void mb_count_kernel(MbWork w) {
 __global__ __launch_bounds__(MB_BLOCK) void mb_write_kernel(MbWork w, uint32_t u, uint32_t m, uint64_t* edges,
                                                              uint32_t* nodes, uint32_t* count_out) {
   __shared__ uint32_t part[MB_BLOCK / 64];
+  if (ammsb_desc_skip(w.desc)) return;  // (block-uniform) a skipped mini-batch leaves the buffers and counters alone
   if (w.desc) u = w.desc->u;
   uint32_t before = 0;
   for (uint32_t i = threadIdx.x; i < blockIdx.x; i += MB_BLOCK) before += w.blk[i];
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(MB_BLOCK) void mb_write_kernel(MbWork w, uint32_t u
 // graph is also not ordered reliably before the graph's first kernel on this runtime), (2) memory-safe tail
 // when fewer than m candidates survived (the caller sees count < m and the sticky counter).
 __global__ void mb_finish_kernel(uint32_t m, const uint32_t* count, uint64_t* edges, uint32_t* nodes, uint64_t* table,
-                                 uint32_t H) {
+                                 uint32_t H, const ammsb_step_desc* desc) {
+  if (ammsb_desc_skip(desc)) return;  // nothing was drawn: the table is still empty, the buffers are not ours
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
   for (uint32_t h = tid; h < H; h += nthreads) table[h] = EMPTY;
   const uint32_t c = count[0];
@@ -188,6 +190,7 @@ __global__ void mb_finish_kernel(uint32_t m, const uint32_t* count, uint64_t* ed
 
 __global__ void mb_link_kernel(const uint64_t* offsets, const uint32_t* targets, uint32_t u, uint32_t n,
                                uint64_t* edges, uint32_t* nodes, const ammsb_step_desc* desc) {
+  if (ammsb_desc_skip(desc)) return;
   if (desc) {  // captured graph: the grid covers the largest degree
     u = desc->u;
     n = desc->n_edges;
@@ -267,7 +270,7 @@ static int minibatch_nonlink_common(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t 
                                          heldout_set ? *heldout_set : none, heldout_set ? 1 : 0);
   mb_count_kernel<<<nb, MB_BLOCK, 0, s>>>(w);
   mb_write_kernel<<<nb, MB_BLOCK, 0, s>>>(w, u, m, edges_out, nodes_out, count_out);
-  mb_finish_kernel<<<64, 256, 0, s>>>(m, count_out, edges_out, nodes_out, w.table, w.H);
+  mb_finish_kernel<<<64, 256, 0, s>>>(m, count_out, edges_out, nodes_out, w.table, w.H, desc);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
   const int slot = Grp::slot();
   uint32_t* s_nb = s_nb_all + slot * a.n;
   const PhiStep st = phi_step(a);
+  if (st.n_nodes == 0) return;  // (uniform) a skipped step
   note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
   const uint32_t g = a.group_begin + blockIdx.x * Grp::PER_BLOCK + slot;
   const bool live = g < st.group_end;
@@ -940,6 +941,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT <= 8 ? 4
   auto lds_col = [&](int j) -> int { return (j >> 2) * 256 + h * 128 + l + 32 * (j & 3); };
 
   const PhiStep st = phi_step(a);
+  if (st.n_nodes == 0) return;  // (uniform) a skipped step
   note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
   const uint32_t g = a.group_begin + blockIdx.x * 2 + h;  // this half's virtual group
   const bool live = g < st.group_end;

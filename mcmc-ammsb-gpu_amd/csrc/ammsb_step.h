@@ -34,6 +34,14 @@ struct ammsb_step_desc {
   uint32_t step;     // step_count (1-based), index of the optional timestamps
 };
 
+// A descriptor with n_nodes == 0 is a SKIP: the step (or the mini-batch) is not to be run.  The loop's device-side
+// hand-over hands skips on once one of its waits has given up (ammsb_loop.hip): every kernel of both chains then leaves
+// the model state, the stream states and the sample buffers untouched, so that the host finds the state of the last
+// COMPLETED step and resumes from it.
+#ifdef __HIPCC__
+static __device__ __forceinline__ bool ammsb_desc_skip(const ammsb_step_desc* d) { return d && d->n_nodes == 0; }
+#endif
+
 // what update_theta does last in a captured step: hand the next two descriptors of the ring to the graph
 // that runs next (which has the other buffer parity), and advance the cursor
 struct ammsb_step_advance {

@@ -187,6 +187,7 @@ class Learner:
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if not cfg.device_sampling else None
         self.dev_sampler = None
         self.loop = None
+        self._loop_dirty = False
         if cfg.device_sampling:
             off, tgt = dataset.training_csr()
             # held-out links of a vertex are invalid non-link partners too (sample.cc:283-285)
@@ -460,6 +461,7 @@ class Learner:
                 raise AmmsbError("graph_launch: the pending mini-batch was not drawn by the device sampler")
             nxt = smp.choose_many(cfg.strategy, n)
             self.loop.run(s.choice, nxt, phi.count_calls + 1, self.phase)
+            self._loop_dirty = True
             # mini-batch edges of the n steps just enqueued: the pending choice, then all but the last new one
             m = cfg.mini_batch_size
             ne = np.where(nxt["link"][:-1] != 0, nxt["n"][:-1], m).astype(np.int64)
@@ -544,7 +546,21 @@ class Learner:
     def HeldoutPerplexity(self):
         return self._perplexity(self.heldoutPerplexity)
 
+    def _check_loop(self):
+        """Before anything reads the model state after descriptor-loop runs: had a device-side wait given up, the
+        steps behind it were skipped, and ammsb_loop_check re-runs them on the event hand-over (ops.GraphLoop.check);
+        a checkpoint or a perplexity taken before that would be of a state some iterations short."""
+        if self.loop is not None and self._loop_dirty:
+            self.loop.check()
+            self._loop_dirty = False
+
+    @property
+    def loop_fallbacks(self):
+        """runs of the descriptor loop that had to be finished on the stream-event hand-over (0 in a healthy run)"""
+        return self.loop.status()[1] if self.loop is not None else 0
+
     def _perplexity(self, calc):
+        self._check_loop()
         t1 = time.perf_counter()
         calc.count_calls += 1
         H = calc.num_edges
@@ -630,6 +646,7 @@ class Learner:
         if two and self.futures[self.phase] is None:
             self._launch_sample(self.phase)  # the reference's constructor has it in flight already
         weight = float(self.futures[self.phase].result()) if two else 0.0  # learner.cc:307-314
+        self._check_loop()
         self.ops.synchronize()
         if self.dev_sampler is not None:
             self.dev_sampler.check()
@@ -716,6 +733,7 @@ class Learner:
         self.ops.synchronize()
         if self.loop is not None:
             self.loop.check()
+            self._loop_dirty = False
         if self.dev_sampler is not None:
             self.dev_sampler.check()  # a mini-batch that came up short is an error, never a silent duplicate
 
@@ -729,5 +747,6 @@ class Learner:
         if self.loop is not None:
             self.loop.close()
             self.loop = None
+        self._loop_dirty = False
         if self.pool is not None:
             self.pool.shutdown(wait=True)

@@ -672,13 +672,21 @@ class GraphLoop:
                                                    int(first_step), int(parity), _stream()))
 
     def check(self):
-        """Synchronises the loop's streams; raises if a device-side wait between the two chains gave up (never in a
-        correct run: the steps since the last check would have used unfinished mini-batches)."""
+        """Synchronises the loop's streams.  If a device-side wait between the two chains gave up, the library has
+        skipped what came after it, switched to the stream-event hand-over and re-run the missing steps by the time
+        this returns (ammsb_loop_check; status() counts the fallback); raises only if that recovery failed."""
         n = C.c_uint32(0)
         self.ctx.check(self.ctx.lib.ammsb_loop_check(self._h, C.byref(n)))
         if n.value:
-            raise AmmsbError("graph loop: %d device-side wait(s) timed out (a kernel-serialising profiler? set "
-                             "AMMSB_LOOP_HANDSHAKE=event)" % n.value)
+            raise AmmsbError("graph loop: %d device-side wait(s) timed out and the run could not be resumed on the "
+                             "event hand-over" % n.value)
+
+    def status(self):
+        """(event_handover, fallbacks): whether the chains are ordered with stream events, and how many runs had to be
+        finished that way after a device-side wait gave up."""
+        ev, fb = C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(self.ctx.lib.ammsb_loop_status(self._h, C.byref(ev), C.byref(fb)))
+        return bool(ev.value), int(fb.value)
 
     def timestamps(self, first_step, n):
         """(begin_ns, end_ns) arrays of update_phi for steps first_step .. first_step + n - 1.  Synchronises."""
