@@ -6,6 +6,8 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <rccl/rccl.h>
+#include <errno.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -75,18 +77,36 @@ struct Star {
       const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
       if (ls < 0) Fail("socket()");
       setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-      sa.sin_addr.s_addr = htonl(INADDR_ANY);
-      if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof sa) != 0) Fail("bind() on the exchange port failed");
+      // listen on MASTER_ADDR only (loopback for a single node): nothing outside the job's own network can connect
+      if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof sa) != 0)
+        Fail("bind() on the exchange port " + std::to_string(port) +
+             " failed (MASTER_PORT + 1 taken? pass a free AMMSB_EXCHANGE_PORT to every rank)");
       if (::listen(ls, world) != 0) Fail("listen()");
       fds.assign(world, -1);
-      for (int i = 1; i < world; ++i) {
+      // the peers retry for a minute; so does this side: a rank that died before connecting must not hang rank 0
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(EnvInt("AMMSB_EXCHANGE_TIMEOUT_S", 60));
+      for (int got = 1; got < world;) {
+        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+        if (left <= 0) Fail("rendezvous timed out: " + std::to_string(world - got) + " rank(s) never connected");
+        pollfd pf = {ls, POLLIN, 0};
+        const int pr = ::poll(&pf, 1, static_cast<int>(left < 1000 ? left : 1000));
+        if (pr < 0 && errno != EINTR) Fail("poll()");
+        if (pr <= 0) continue;
         const int fd = ::accept(ls, nullptr, nullptr);
-        if (fd < 0) Fail("accept()");
+        if (fd < 0) continue;
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+        timeval tv = {5, 0};  // a connection that says nothing for 5 s is not one of ours
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
         int peer = -1;
-        RecvAll(fd, &peer, sizeof peer);
-        if (peer <= 0 || peer >= world || fds[peer] != -1) Fail("unexpected peer rank at rendezvous");
+        const ssize_t k = ::recv(fd, &peer, sizeof peer, MSG_WAITALL);
+        if (k != static_cast<ssize_t>(sizeof peer) || peer <= 0 || peer >= world || fds[peer] != -1) {
+          ::close(fd);  // a stray connection (port scanner, a rank of another job): ignore it, keep waiting
+          continue;
+        }
+        timeval none = {0, 0};
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
         fds[peer] = fd;
+        ++got;
       }
       ::close(ls);
     } else {

@@ -317,21 +317,29 @@ class Learner:
         X = min(ops.elapsed_ms(lambda: t_xchg("collective")) for _ in range(3)) * scale
         x_p2p = None
         if self.xchg_mode == "auto" and R > 1 and not ops._via_host(dist, self.group):
-            # the direct form (one send per peer and link): time it, and check it against the collective's result
+            # The direct form (one send per peer and link): time it, and check its result against the collective's --
+            # whole rows, on EVERY rank.  No exception is swallowed here: a rank that failed inside a batch of
+            # point-to-point operations leaves its peers blocked in theirs, and the communicator in an undefined state;
+            # that ends the run (loudly) instead of a later collective hanging.
             ops.synchronize()
-            want = region.double().sum(dim=1)
-            try:
-                x_p2p = min(ops.elapsed_ms(lambda: t_xchg("p2p")) for _ in range(3)) * scale
-                ops.synchronize()
-                if not torch.equal(region.double().sum(dim=1), want):
-                    x_p2p = None
-            except Exception:  # a backend without batched point-to-point: stay with the collective
+            want = region.clone()
+            x_p2p = min(ops.elapsed_ms(lambda: t_xchg("p2p")) for _ in range(3)) * scale
+            ops.synchronize()
+            ok = torch.equal(region, want)
+            del want
+            # one verdict for the whole job: usable only if it was right everywhere, and rank 0's timing decides
+            v = torch.tensor([1.0 if ok else 0.0, x_p2p if self.rank == 0 else 0.0, X if self.rank == 0 else 0.0],
+                             dtype=torch.float64).to(c.device)
+            allv = torch.zeros((R, 3), dtype=torch.float64).to(c.device)
+            ops.all_gather_flat(dist, allv, v, self.rank, R, self.group)
+            allv = allv.cpu()
+            all_ok = bool((allv[:, 0] > 0.5).all())
+            x_p2p, X = float(allv[0, 1]), float(allv[0, 2])
+            if not all_ok:
                 x_p2p = None
         use_p2p = x_p2p is not None and x_p2p < 0.97 * X
         if self.xchg_mode == "auto":
-            flag = torch.tensor([1.0 if use_p2p else 0.0], dtype=torch.float64).to(c.device)
-            ops.wait_work(ops.broadcast_async(dist, flag, 0, self.group))   # every rank takes rank 0's choice
-            self.xchg_mode = "p2p" if float(flag.item()) > 0.5 else "collective"
+            self.xchg_mode = "p2p" if use_p2p else "collective"   # the same inputs on every rank: the same choice
         if self.xchg_mode == "p2p" and x_p2p is not None:
             X = x_p2p
         phi.rand.seeds.copy_(keep)
@@ -347,8 +355,12 @@ class Learner:
         t = torch.tensor([rho], dtype=torch.float64)
         t = t.to(c.device)
         ops.wait_work(ops.broadcast_async(dist, t, 0, self.group))
-        self.calibration = {"phi_ms": T, "xchg_ms": X, "rho": float(t.item()), "exchange": self.xchg_mode,
-                            "xchg_p2p_ms": x_p2p}
+        rho_f = float(t.item())
+        self.calibration = {"phi_ms": T, "xchg_ms": X, "rho": rho_f, "exchange": self.xchg_mode,
+                            "xchg_p2p_ms": x_p2p,
+                            # what the split is expected to buy on update_phi alone: full launch / max(compute, exchange)
+                            "predicted_phi_ms": cost(rho_f), "predicted_phi_speedup": T / cost(rho_f) if cost(rho_f) > 0 else None,
+                            "pure_sharding_phi_speedup": T / cost(0.0) if cost(0.0) > 0 else None}
         self._set_split(int(float(t.item()) * MAX_GROUPS))
         ops.synchronize()
 

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -53,3 +55,27 @@ def test_spawned_children_failure_is_relayed():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
     assert '"metric"' not in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_bench_two_ranks_end_to_end():
+    """`python bench.py --gpus 2 --workload C1` exactly as the driver types it (no launcher): the parent starts the two
+    ranks itself, they rendezvous on 127.0.0.1, run the sharded learner and rank 0 prints ONE JSON line.  On a one-GPU
+    box the ranks share the device and the exchange is staged through host memory (AMMSB_BENCH_BACKEND=gloo -- RCCL
+    refuses two ranks on one device): a rehearsal of the code path, labelled as such in the line, never a number."""
+    import json
+    env = dict(os.environ, AMMSB_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "C1", "--steps", "30", "--warmup", "5",
+                          "--no-cpu-baseline", "--cpp-dropin", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 0 and "REHEARSAL" in rec["data"]
+    assert rec["steps"] == 30 and rec["value"] > 0 and rec["scaling"] == "strong"
+    split = rec["config"]["phi_split"]
+    assert split is not None and split["exchange"] in ("collective", "p2p") and 0.0 <= split["rho"] <= 1.0
+    assert split["predicted_phi_speedup"] is None or split["predicted_phi_speedup"] > 0
+    assert rec["config"]["parallelism"].endswith("x2")

@@ -32,11 +32,11 @@ def _free_port():
 
 def _ranks(argv, world, timeout=600, per_rank_args=None):
     """Start `world` copies of argv, one per rank, all on device 0; returns the CompletedProcess-like results."""
-    port = _free_port()
+    port, xport = _free_port(), _free_port()   # the launcher hands the rendezvous its own free port (not MASTER_PORT + 1)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), AMMSB_EXCHANGE_PORT=str(xport), HSA_ENABLE_IPC_MODE_LEGACY="0")
         extra = per_rank_args(r) if per_rank_args else []
         procs.append(subprocess.Popen(argv + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     out = []
@@ -71,6 +71,43 @@ def test_bad_rank_is_an_error(built):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1")
     r = subprocess.run([XT, "carrier-pigeon", "hostmem"], env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "unknown exchange kind" in r.stderr
+
+
+def test_rendezvous_gives_up_on_a_missing_peer_and_ignores_strays(built):
+    """Rank 0 of a 2-rank job whose peer never starts must fail after the time-out, not hang; a stray
+    connection to the rendezvous port (not one of the job's ranks) is dropped, not fatal."""
+    xport = _free_port()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               AMMSB_EXCHANGE_PORT=str(xport), AMMSB_EXCHANGE_TIMEOUT_S="3")
+    p = subprocess.Popen([XT, "host", "hostmem"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import time
+    for _ in range(50):  # a stray: connects, sends a nonsense rank
+        try:
+            with socket.create_connection(("127.0.0.1", xport), timeout=1) as c:
+                c.sendall((12345).to_bytes(4, "little"))
+            break
+        except OSError:
+            time.sleep(0.1)
+    o, e = p.communicate(timeout=60)
+    assert p.returncode != 0 and "rendezvous timed out: 1 rank(s) never connected" in e, (o, e)
+    # a real peer after a stray is accepted
+    xport = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                   AMMSB_EXCHANGE_PORT=str(xport))
+        procs.append(subprocess.Popen([XT, "host", "hostmem"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        if r == 0:
+            for _ in range(50):
+                try:
+                    with socket.create_connection(("127.0.0.1", xport), timeout=1) as c:
+                        c.sendall((-7).to_bytes(4, "little", signed=True))
+                    break
+                except OSError:
+                    time.sleep(0.1)
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0 and o.startswith("OK"), (r, o, e)
 
 
 @pytest.mark.gpu
