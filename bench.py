@@ -395,6 +395,13 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
                                            "what": "the main chain's last kernel polling for the next mini-batch"}
             kernels["source"] = ("device stamps of the %d non-link steps of the timed window; each duration includes one "
                                  "kernel boundary" % int(ok.sum()))
+            okl = (~nl) & (st[:, 0] > 0) & (st[:, 5] >= st[:, 4]) & (st[:, 4] >= st[:, 3]) & (st[:, 3] >= st[:, 2]) & \
+                (st[:, 2] >= st[:, 1]) & (st[:, 1] >= st[:, 0])
+            if okl.any():  # link steps (a few dozen nodes: latency, not bytes): where their time goes
+                dl = lambda a, b: round(float((st[okl, b] - st[okl, a]).mean()) * 1e-6, 5)  # noqa: E731  (ms)
+                kernels["link_steps_ms"] = {"update_phi": dl(0, 1), "update_pi": dl(1, 2), "beta_grads": dl(2, 3),
+                                            "sum_grads+update_theta": dl(3, 4), "wait_for_sampler": dl(4, 5),
+                                            "steps": int(okl.sum())}
     else:
         launches = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev]
     big = [(t, nn, g) for t, nn, g in launches if nn > m // 2]

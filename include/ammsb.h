@@ -79,6 +79,8 @@ typedef struct ammsb_ctx ammsb_ctx;
 
 /* flags for ammsb_update_phi / ammsb_update_theta */
 #define AMMSB_NOISE_OFF 1u /* Config::phi_disable_noise: PHI_RANDN(X) := 1, phi.cc:673-677 */
+#define AMMSB_PHI_STREAMING 2u /* ammsb_update_phi only: take the throughput (one wave per node) kernels even for a launch
+                                * small enough for the latency form (one node per multi-wave block); same results */
 
 int ammsb_version(void);
 const char* ammsb_strerror(int code);

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("AMMSB_HIP_LIB") or os.path.join(_HERE, "libammsb_hip.
 RPM_MAX_BLOCKS = 32
 MAX_GROUPS = 65535
 NOISE_OFF = 1
+PHI_STREAMING = 2  # AMMSB_PHI_STREAMING
 
 
 class AmmsbError(RuntimeError):

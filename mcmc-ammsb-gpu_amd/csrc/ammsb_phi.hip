@@ -1183,6 +1183,176 @@ int launch_phi_pair(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
   return AMMSB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small launches (link mini-batches: a few dozen nodes on an otherwise empty chip): ONE NODE PER BLOCK OF RW + 1 WAVES.
+//
+// A lone wave working through a node is a latency chain: n neighbour rows one after the other (load, probs, WG_SUM
+// tree, reciprocal, two divisions each) and then K / wg ziggurat draws per lane -- 19 us at K = 256, 50 us at K = 1024
+// whatever the ring depth, and half of all iterations are such launches.  What is sequential in the
+// reference is only the ACCUMULATION grads_k += term_q,k over the neighbours q = 0 .. n-1 (phi.cc:259-263) and the
+// draw order inside one RNG stream; the terms themselves are independent.  So here the first RW waves of the block take
+// the rows round-robin (wave w: q = w, w + RW, ...), each one running the one-wave-per-node arithmetic on its row --
+// same lane ownership, same WG_SUM chain and tree (VLane<VL>), same exact divisions -- and parking the row's term
+// vector in LDS; the last wave meanwhile draws the node's normals (stream order = ascending column, as everywhere);
+// then every thread takes some columns, adds their n terms IN ROW ORDER starting from 0 (the reference's accumulation,
+// bit for bit) and makes the SGLD step for them.  LDS: n K floats of terms (128 KiB at K = 1024, n = 32: one block per
+// CU, which is all a link batch needs).
+template <int KPT, int RW, int VL>
+__global__ __launch_bounds__(64 * (RW + 1)) void update_phi_wide_kernel(const PhiArgs a) {
+  constexpr int K = 64 * KPT, T = 64 * (RW + 1);
+  using VLn = VLane<VL>;
+  constexpr int KV = KPT * VLn::PER;  // normals per virtual lane
+  extern __shared__ __align__(16) char smem[];  // [n][K] terms, [K] normals, [K] pi_a, [n] u32 (id | link bit)
+  __shared__ ZigTables zig;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const uint32_t n = a.n;
+  float* term = reinterpret_cast<float*>(smem);
+  float* s_noise = term + (size_t)n * K;
+  float* s_pia = s_noise + K;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(s_pia + K);
+
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
+  const uint32_t g = a.group_begin + blockIdx.x;
+  if (g >= st.group_end) return;  // block-uniform
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  float bf[KPT];
+  bool beta_safe = true;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const float b = a.beta[2 * (ln + 64 * j) + 1];
+    bf[j] = b - EPS;
+    beta_safe = beta_safe && in_range(b, EPS, kBetaHi);
+  }
+  ammsb_seed rs = {0, 0};
+  const bool noise_wave = wv == RW;
+  if (a.noise_on && noise_wave) rs = a.seeds[(uint64_t)g * VL + VLn::vlane(ln)];
+
+  for (uint64_t i = g; i < st.n_nodes; i += st.G) {
+    const uint32_t node = a.nodes[i];
+    __syncthreads();  // orders the LDS traffic of consecutive nodes
+    for (uint32_t q = tid; q < n; q += T) {
+      const uint32_t nbq = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nbq));
+      s_nb[q] = nbq | (y ? 0x80000000u : 0u);
+    }
+    const float phi_sum = a.phi_sum[node];
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = rpm_row(a.pi, node);
+    float pi_a[KPT], rden[KPT];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) pi_a[j] = row_a[ln + 64 * j];
+    if (noise_wave) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) s_pia[ln + 64 * j] = pi_a[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const float den = pi_a[j] * phi_sum;
+        rden[j] = exact_rcp(den);
+        node_safe = node_safe && in_range(den, kDenLo, kDenHi);
+      }
+    }
+    __syncthreads();  // s_nb complete
+
+    if (!noise_wave) {
+      // this wave's rows: q = wv, wv + RW, ...; the next row's loads are issued before the current row is reduced
+      float cur[KPT], nxt[KPT];
+      auto load_row = [&](float (&dst)[KPT], uint32_t q) {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(s_nb[q < n ? q : n - 1] & 0x7fffffffu);
+        const float* row = rpm_row(a.pi, w);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) dst[j] = __builtin_nontemporal_load(row + ln + 64 * j);
+      };
+      if ((uint32_t)wv < n) load_row(cur, wv);
+      for (uint32_t q = wv; q < n; q += RW) {
+        load_row(nxt, q + RW);  // unconditional (clamped): the last trip re-requests the last row
+        const bool y = __builtin_amdgcn_readfirstlane(s_nb[q] >> 31) != 0;
+        const float e = y ? EPS : 1.0f - EPS;
+        float pr[KPT];
+        float partial = 0.0f, lo = 1.0f;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {  // phi.cc:241-253 (columns ascending: j = 0, 1, ... is this lane's chain order)
+          const float tt0 = cur[j] * bf[j];
+          const float tt = y ? tt0 + e : e - tt0;
+          pr[j] = pi_a[j] * tt;
+          VLn::chain(partial, pr[j]);
+          lo = fminf(lo, fabsf(pr[j]));
+        }
+        const float probs_sum = VLn::tree(partial);  // phi.cc:254-257
+        float* tq = term + (size_t)q * K;
+        // phi.cc:259-263: the row's contribution (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
+        if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+          const float rps = exact_rcp(probs_sum);
+#pragma unroll
+          for (int j = 0; j < KPT; ++j) {
+            float qv = div_exact3(pr[j], probs_sum, rps);
+            qv = div_exact3(qv, pi_a[j] * phi_sum, rden[j]);
+            tq[ln + 64 * j] = qv - inv_phi_sum;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < KPT; ++j) {
+            float qv = pr[j] / probs_sum;
+            qv = qv / (pi_a[j] * phi_sum);
+            tq[ln + 64 * j] = qv - inv_phi_sum;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) cur[j] = nxt[j];
+      }
+    } else if (a.noise_on) {
+      // the node's normals: virtual lane's draw number j belongs to physical column j / PER of the lane that keeps it
+#pragma unroll 1
+      for (uint32_t j = 0; j < (uint32_t)KV; ++j) {
+        const float z = rng_normal(rs, &zig);
+        if (VLn::keeps(ln, j)) s_noise[ln + 64 * (j / VLn::PER)] = z;
+      }
+    }
+    __syncthreads();  // all terms, the normals and pi_a are in LDS
+
+    // columns tid, tid + T, ...: accumulate the n terms in row order (grads = ((0 + t_0) + t_1) + ...), then the SGLD
+    // step of phi.cc:265-274
+    float* out = a.phi_vec + i * K;
+    const float half = st.eps_t / 2;
+    for (int c = tid; c < K; c += T) {
+      float grads = 0.0f;
+      for (uint32_t q = 0; q < n; ++q) grads += term[(size_t)q * K + c];
+      const float noise = a.noise_on ? s_noise[c] : 1.0f;
+      const float phi_k = s_pia[c] * phi_sum;
+      const float ng = a.Nn * grads;
+      float in = a.alpha - phi_k;
+      in = in + ng;
+      const float drift = half * in;
+      const float aa = phi_k + drift;
+      const float ep = st.eps_t * phi_k;
+      const float sq = sqrtf(ep);
+      const float bb = sq * noise;
+      const float v = fabsf(aa + bb);
+      out[c] = v > 1e-24f ? v : 1e-24f;
+    }
+  }
+  if (a.noise_on && noise_wave && ln < VL) a.seeds[(uint64_t)g * VL + ln] = rs;
+}
+
+template <int KPT, int RW, int VL>
+int launch_phi_wide(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = sizeof(float) * 64 * KPT * ((size_t)a.n + 2) + sizeof(uint32_t) * a.n;
+  static const bool big = [] {  // more than the default 64 KiB of dynamic LDS: once per instantiation
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(update_phi_wide_kernel<KPT, RW, VL>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) == hipSuccess;
+  }();
+  (void)big;
+  static const std::string name = ammsb_kname("update_phi_wide_kernel<%d, %d, %d>", KPT, RW, VL);
+  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
+  update_phi_wide_kernel<KPT, RW, VL><<<n_groups, 64 * (RW + 1), lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 template <int KPT, int D, int U, int VL = 64>
 int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
@@ -1575,6 +1745,24 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
   }();
+  // Small launches (link mini-batches): one node per block of 8 row waves + a noise wave (update_phi_wide_kernel).
+  // AMMSB_PHI_WIDE=0 turns it off; the value is the largest launch (in nodes) that takes it.
+  static const uint32_t wide_max = [] {
+    const char* f = getenv("AMMSB_PHI_WIDE");
+    return f ? (uint32_t)atoi(f) : 512u;
+  }();
+  if (n_groups <= wide_max && !(flags & AMMSB_PHI_STREAMING) && !force_reg && !force_gen && (wg == 32 || wg == 64) &&
+      (p.K == 256 || p.K == 512 || p.K == 1024) && a.n >= 1 && n_nodes <= AMMSB_MAX_GROUPS &&
+      sizeof(float) * p.K * ((size_t)a.n + 2) + sizeof(uint32_t) * a.n <= 150 * 1024) {
+    if (wg == 64) {
+      if (p.K == 256) return launch_phi_wide<4, 8, 64>(ctx, a, n_groups, s);
+      if (p.K == 512) return launch_phi_wide<8, 8, 64>(ctx, a, n_groups, s);
+      return launch_phi_wide<16, 8, 64>(ctx, a, n_groups, s);
+    }
+    if (p.K == 256) return launch_phi_wide<4, 8, 32>(ctx, a, n_groups, s);
+    if (p.K == 512) return launch_phi_wide<8, 8, 32>(ctx, a, n_groups, s);
+    return launch_phi_wide<16, 8, 32>(ctx, a, n_groups, s);
+  }
   // Short rows, two nodes per wave (update_phi_pair_kernel): K = 256 / 512 at wg 32 or 64, n a multiple of 2.
   // Opt-in (AMMSB_PHI_PAIR=1; 2 / 3 pick other ring depths / rows per step): bit-identical, but SLOWER at C2 in same-box
   // A/B runs -- 110 / 89 us (wg 64 / 32) against 70 / 79 us for the one-node-per-wave kernels, link steps 50 against

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import AmmsbError, NOISE_OFF, Params, PpxSums, Rpm, SetDesc, check
+from ._capi import AmmsbError, NOISE_OFF, PHI_STREAMING, Params, PpxSums, Rpm, SetDesc, check
 
 SEED_DT = np.dtype([("x", np.uint64), ("y", np.uint64)])
 
@@ -316,10 +316,11 @@ class PhiUpdater:
     """phi.h:10-61 / phi.cc:608-763.  mode is always the work-group form on this hardware."""
 
     def __init__(self, ctx, beta, pi, phi, training_set, max_nodes, phi_seed=(42, 43), phi_wg_size=64,
-                 phi_disable_noise=False):
+                 phi_disable_noise=False, streaming_only=False):
         self.ctx, self.beta, self.pi, self.phi, self.set = ctx, beta, pi, phi, training_set
         self.local = int(phi_wg_size)
-        self.flags = NOISE_OFF if phi_disable_noise else 0
+        # streaming_only: small launches too go through the one-wave-per-node kernels (AMMSB_PHI_STREAMING)
+        self.flags = (NOISE_OFF if phi_disable_noise else 0) | (PHI_STREAMING if streaming_only else 0)
         self.max_nodes = int(max_nodes)
         self.phi_vec = ctx.empty((self.max_nodes, ctx.params.K), torch.float32)
         # phi.cc:625-629: max(2m, 1+maxdeg) * wg streams

@@ -157,7 +157,7 @@ for N, K, n, n_nodes, L in [(2048, 256, 32, 201, 64), (2048, 256, 32, 200, 32), 
     for noise in (False, True):
         pr = Problem(orc, hip, N, K, n, n_nodes, deg=4 if N > 10000 else 16)
         upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L,
-                             phi_disable_noise=not noise)
+                             phi_disable_noise=not noise, streaming_only=True)
         seeds = orc.rng_init(n_nodes * L, 42, 43)
         pi_h, phi_sum_h = pr.pi_h.copy(), pr.phi_sum_h.copy()
         for step in (1, 2):

@@ -304,15 +304,25 @@ PHI_CASES = [
     (2048, 512, 7, 100, 32),    # update_phi_lds_kernel<8, 1, 4, 1, 32>
     (512, 2048, 8, 40, 32),     # update_phi_lds_kernel<32, 1, 2, 1, 32>: 64 columns per work-item
     (512, 2048, 70, 20, 32),    # more neighbours than normals per virtual lane
+    (1024, 1024, 33, 30, 64),   # link-batch sized launches: n not a multiple of the 8 row waves
+    (1024, 1024, 3, 30, 32),    # fewer neighbours than row waves
+    (1024, 512, 13, 50, 64),
 ]
 
 
+# streaming: the throughput kernels (one wave per node, what a non-link mini-batch runs); small: whatever the library
+# picks for a launch of this size -- up to 512 nodes at K = 256 / 512 / 1024 and wg 32 / 64 that is
+# update_phi_wide_kernel (one node per block of 9 waves, what a link mini-batch runs)
 @pytest.mark.parametrize("N,K,n,n_nodes,L", PHI_CASES)
 @pytest.mark.parametrize("noise", [False, True])
-def test_update_phi_and_pi(orc, hip, N, K, n, n_nodes, L, noise):
+@pytest.mark.parametrize("form", ["streaming", "small"])
+def test_update_phi_and_pi(orc, hip, N, K, n, n_nodes, L, noise, form):
+    wide = n_nodes <= 512 and K in (256, 512, 1024) and L in (32, 64) and 4 * K * (n + 2) + 4 * n <= 150 * 1024
+    if form == "small" and not wide:
+        pytest.skip("this launch has one form only")
     pr = Problem(orc, hip, N, K, n, n_nodes)
     upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L,
-                         phi_disable_noise=not noise)
+                         phi_disable_noise=not noise, streaming_only=form == "streaming")
     seeds = orc.rng_init(n_nodes * L, 42, 43)
     pi_h, phi_sum_h = pr.pi_h.copy(), pr.phi_sum_h.copy()
     for step in (1, 2):  # second call consumes the carried-over stream states
@@ -324,6 +334,8 @@ def test_update_phi_and_pi(orc, hip, N, K, n, n_nodes, L, noise):
         assert elem_rel_err(got, want) <= FLOAT_TOL
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "expected bit-identical phi_vec"
         assert np.array_equal(upd.rand.host(), seeds)
+        if not os.environ.get("AMMSB_PHI_FORM"):  # (a forced register / generic form has no small-launch kernel)
+            assert ("wide_kernel" in pr.ctx.kernel_names()["update_phi"]) == (form == "small")
         orc.update_pi(pr.p_orc, pi_h.reshape(-1), phi_sum_h, want.reshape(-1), pr.nodes_h, L, 1)
         assert np.array_equal(pr.pi.host().view(np.uint32), pi_h.view(np.uint32))
         assert np.array_equal(pr.phi_sum.cpu().numpy(), phi_sum_h)
@@ -331,8 +343,9 @@ def test_update_phi_and_pi(orc, hip, N, K, n, n_nodes, L, noise):
 
 
 @pytest.mark.parametrize("case", ["floor_pi", "beta_edges", "tiny_phi_sum", "mixed"])
-@pytest.mark.parametrize("L,K", [(64, 1024), (128, 512), (32, 96)])
-def test_update_phi_extreme_values(orc, hip, case, L, K):
+@pytest.mark.parametrize("L,K,streaming", [(64, 1024, True), (64, 1024, False), (32, 512, False), (128, 512, True),
+                                           (32, 96, True)])
+def test_update_phi_extreme_values(orc, hip, case, L, K, streaming):
     """The kernel replaces `x / d` by a hoisted-reciprocal form only inside a proven-safe operand range
     (ammsb_dev.h "exact division"); these inputs sit on and beyond every edge of that range -- pi
     entries at the 1e-24 clamp floor (what a trained model looks like), beta within 1e-8 of 0 and 1,
@@ -361,7 +374,7 @@ def test_update_phi_extreme_values(orc, hip, case, L, K):
         pr.phi_sum_h[1::3] *= np.float32(1e9)
     pr.pi.load(pr.pi_h)
     pr.phi_sum.copy_(pr.ctx.from_numpy(pr.phi_sum_h))
-    upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L)
+    upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L, streaming_only=streaming)
     seeds = orc.rng_init(n_nodes * L, 42, 43)
     upd.count_calls = 1
     upd.update_phi(pr.nodes, pr.nb, n_nodes)
