@@ -183,7 +183,11 @@ int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, con
  *      sample.cc:177-303 + learner.cc:162-185, which caps throughput once the kernels are fast) ----
  * Strategy "Node" (stratified random node, sample.cc:295-303) split in its two halves; the caller
  * flips the coin and picks u on the host, so that the mini-batch sizes are known without a device
- * round trip.  Same distribution as the host samplers, not the same random stream. */
+ * round trip.  Same distribution as the host samplers, not the same random stream.
+ * SCOPE: the Node family only (Node, NodeLink, NodeNonLink).  The breadth-first strategies (BFLink, BFNonLink, BF,
+ * sample.cc:177-247) are a serial frontier walk over a queue -- every pick depends on what the walk has visited -- and
+ * stay on the host: mcmc::sampleBreadthFirst* (host/sample.cc, bit-identical to the reference's rand_r stream) feed
+ * the same device buffers through Learner::DoSample; none of BASELINE.json's configurations uses them. */
 
 /* sampleNodeLink's edge set for vertex u: all training edges (u, v), v in CSR order.  n = deg(u) =
  * offsets[u+1] - offsets[u] must be > 0.  edges_out[n], nodes_out[n+1] = {u, v_0, ...}. */

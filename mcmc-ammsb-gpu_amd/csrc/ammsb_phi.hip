@@ -1754,14 +1754,19 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   if (n_groups <= wide_max && !(flags & AMMSB_PHI_STREAMING) && !force_reg && !force_gen && (wg == 32 || wg == 64) &&
       (p.K == 256 || p.K == 512 || p.K == 1024) && a.n >= 1 && n_nodes <= AMMSB_MAX_GROUPS &&
       sizeof(float) * p.K * ((size_t)a.n + 2) + sizeof(uint32_t) * a.n <= 150 * 1024) {
+    // row waves per node: 15 (+ the noise wave = 1024 threads) while 128 registers hold a lane's state, 11 at K = 1024
+    static const int rw_alt = [] {  // AMMSB_PHI_WIDE_RW=8: the eight-row-wave blocks (A/B runs)
+      const char* f = getenv("AMMSB_PHI_WIDE_RW");
+      return f ? atoi(f) : 0;
+    }();
     if (wg == 64) {
-      if (p.K == 256) return launch_phi_wide<4, 8, 64>(ctx, a, n_groups, s);
-      if (p.K == 512) return launch_phi_wide<8, 8, 64>(ctx, a, n_groups, s);
-      return launch_phi_wide<16, 8, 64>(ctx, a, n_groups, s);
+      if (p.K == 256) return rw_alt == 8 ? launch_phi_wide<4, 8, 64>(ctx, a, n_groups, s) : launch_phi_wide<4, 15, 64>(ctx, a, n_groups, s);
+      if (p.K == 512) return rw_alt == 8 ? launch_phi_wide<8, 8, 64>(ctx, a, n_groups, s) : launch_phi_wide<8, 11, 64>(ctx, a, n_groups, s);
+      return rw_alt == 8 ? launch_phi_wide<16, 8, 64>(ctx, a, n_groups, s) : launch_phi_wide<16, 11, 64>(ctx, a, n_groups, s);
     }
-    if (p.K == 256) return launch_phi_wide<4, 8, 32>(ctx, a, n_groups, s);
-    if (p.K == 512) return launch_phi_wide<8, 8, 32>(ctx, a, n_groups, s);
-    return launch_phi_wide<16, 8, 32>(ctx, a, n_groups, s);
+    if (p.K == 256) return rw_alt == 8 ? launch_phi_wide<4, 8, 32>(ctx, a, n_groups, s) : launch_phi_wide<4, 15, 32>(ctx, a, n_groups, s);
+    if (p.K == 512) return rw_alt == 8 ? launch_phi_wide<8, 8, 32>(ctx, a, n_groups, s) : launch_phi_wide<8, 11, 32>(ctx, a, n_groups, s);
+    return rw_alt == 8 ? launch_phi_wide<16, 8, 32>(ctx, a, n_groups, s) : launch_phi_wide<16, 11, 32>(ctx, a, n_groups, s);
   }
   // Short rows, two nodes per wave (update_phi_pair_kernel): K = 256 / 512 at wg 32 or 64, n a multiple of 2.
   // Opt-in (AMMSB_PHI_PAIR=1; 2 / 3 pick other ring depths / rows per step): bit-identical, but SLOWER at C2 in same-box

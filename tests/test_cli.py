@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "mcmc-ammsb-gpu_amd", "ammsb_main")
+EXE = os.environ.get("AMMSB_MAIN_EXE") or os.path.join(ROOT, "mcmc-ammsb-gpu_amd", "ammsb_main")  # (tools/run_asan.sh)
 
 # every option of the reference's CLI (main.cc:43-81) with its short form and default
 REFERENCE_FLAGS = [
@@ -141,3 +141,35 @@ def test_cli_reference_default_work_groups_at_k1024(exe, tmp_path, loop):
     assert [s for s, _ in ppx] == [0, 20, 40]
     assert all(np.isfinite(p) and p > 1.0 for _, p in ppx)
     assert re.search(r"^TOTAL *:", run.stderr, re.M)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loop", [["--async", "1"], ["--async", "1", "--graph", "1"]])
+def test_print_stats_categories_in_the_enqueue_only_loops(exe, tmp_path, loop):
+    """learner.cc:252-299: the per-kernel categories of PrintStats must carry device time under --async (event pairs
+    read back at the drain) and --graph (time stamps the kernels write themselves), not zeros; --loop-timers 0 turns
+    them off."""
+    g, d = str(tmp_path / "g.txt"), str(tmp_path / "g.bin.gz")
+    _snap_file(g)
+    common = ["-k", "64", "-m", "128", "-n", "16", "-r", "0.05", "--phi-wg", "64", "--beta-wg", "64", "--ppx-wg", "64",
+              "--device-sampling", "1", "-x", "300", "-i", "300"]
+    r = subprocess.run([exe, "-f", g, "--dump-data", "1", "--dump-file", d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([exe, "--load-data", "1", "--load-file", d] + common + loop, capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+
+    def cat(text, name):
+        m = re.search(r"^%s *: ([0-9.eE+-]+)" % re.escape(name), text, re.M)
+        assert m, name
+        return float(m.group(1))
+    total = cat(run.stderr, "TOTAL")
+    parts = {n: cat(run.stderr, n) for n in ("PHI", "PI", "GRADS PAR", "UPDATE THETA")}
+    assert parts["PHI"] > 0 and parts["GRADS PAR"] > 0 and parts["UPDATE THETA"] > 0, parts
+    assert sum(parts.values()) <= 1.5 * total, (parts, total)   # device time of the chain, not more than the wall time
+    off = subprocess.run([exe, "--load-data", "1", "--load-file", d] + common + loop + ["--loop-timers", "0"],
+                         capture_output=True, text=True, timeout=600)
+    assert off.returncode == 0, off.stderr[-3000:]
+    assert cat(off.stderr, "PHI") == 0 and cat(off.stderr, "GRADS PAR") == 0
+    # the trajectory does not depend on the timers
+    assert _ppx_lines(off.stderr) == _ppx_lines(run.stderr)

@@ -14,7 +14,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "mcmc-ammsb-gpu_amd")
-XT, EXE = os.path.join(PKG, "exchange_test"), os.path.join(PKG, "ammsb_main")
+# (tools/run_asan.sh points these at sanitizer builds)
+XT = os.environ.get("AMMSB_XT_EXE") or os.path.join(PKG, "exchange_test")
+EXE = os.environ.get("AMMSB_MAIN_EXE") or os.path.join(PKG, "ammsb_main")
 
 
 @pytest.fixture(scope="module")

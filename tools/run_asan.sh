@@ -14,3 +14,9 @@ export LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=lib
 export OMP_NUM_THREADS=2
 python -m pytest -x -q -m "not gpu" tests/test_host_lib.py tests/test_oracle_samplers.py tests/test_oracle_pins.py \
     tests/test_checkpoint.py tests/test_oracle_model.py tests/test_golden.py -p no:cacheprovider "$@"
+# the command-line driver (flag parser, SNAP / gzip data-set loaders) and the exchange rendezvous (sockets): the
+# executables themselves are sanitizer builds (make asan), started by the CPU cases of their tests
+unset LD_PRELOAD AMMSB_HOST_LIB AMMSB_ORACLE_LIB
+export AMMSB_MAIN_EXE=$PWD/mcmc-ammsb-gpu_amd/ammsb_main_asan
+export AMMSB_XT_EXE=$PWD/mcmc-ammsb-gpu_amd/exchange_test_asan
+python -m pytest -x -q -m "not gpu" tests/test_cli.py tests/test_cpp_exchange.py -p no:cacheprovider "$@"
