@@ -27,7 +27,7 @@ struct BetaArgs {
   const float* theta;
   const float* beta;
   ammsb_rpm pi;
-  ammsb_set set;
+  DevSet set;  // (ammsb_dev.h: the descriptor + the modulo magic)
   const uint64_t* edges;
   float* partials;   // [P, 2K]
   float* theta_sum;  // [K]
@@ -1055,7 +1055,7 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.theta = theta;
   a.beta = beta;
   a.pi = *pi;
-  a.set = *training_set;
+  a.set = dev_set(*training_set);
   a.edges = edges;
   a.partials = ctx->grad_partials;
   a.theta_sum = ctx->theta_sum;

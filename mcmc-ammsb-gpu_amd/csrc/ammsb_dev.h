@@ -250,6 +250,38 @@ __device__ __forceinline__ bool set_has(const ammsb_set& set, uint64_t k) {
          (c1.x == k) | (c1.y == k);
 }
 
+// The kernels' own view of a set: the public descriptor plus the magic number of fast_mod() for num_bins, computed on
+// the host when a launch is prepared.  hipcc lowers a 64-bit `%` by a run-time divisor to a software loop of several
+// hundred cycles, and a probe needs two of them in front of its (dependent) loads; with the magic a modulo is a 64-bit
+// high multiply and at most two corrections, exact for every operand (see fast_mod).
+struct DevSet {
+  const uint64_t* slots;
+  uint64_t num_bins;
+  FastMod mod;
+  uint32_t prime_idx;
+};
+inline __host__ DevSet dev_set(const ammsb_set& s) {
+  return DevSet{s.slots, s.num_bins, fast_mod_init(s.num_bins ? s.num_bins : 1), s.prime_idx};
+}
+
+// the two bins of key k, as loaded (set_probe) and their comparison with k (set_hit): split so that a caller can put
+// independent work between issuing the loads and needing their result
+struct SetProbe {
+  ulonglong2 a0, a1, c0, c1;
+};
+__device__ __forceinline__ SetProbe set_probe(const DevSet& set, uint64_t k) {
+  const uint64_t h1 = fast_mod(kSetPrimes[2 * set.prime_idx] * k, set.mod);
+  const uint64_t h2 = fast_mod(k ^ kSetPrimes[2 * set.prime_idx + 1], set.mod);
+  const ulonglong2* b1 = reinterpret_cast<const ulonglong2*>(set.slots + h1 * 4);
+  const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(set.slots + (set.num_bins + h2) * 4);
+  return SetProbe{b1[0], b1[1], b2[0], b2[1]};
+}
+__device__ __forceinline__ bool set_hit(const SetProbe& p, uint64_t k) {
+  return (p.a0.x == k) | (p.a0.y == k) | (p.a1.x == k) | (p.a1.y == k) | (p.c0.x == k) | (p.c0.y == k) |
+         (p.c1.x == k) | (p.c1.y == k);
+}
+__device__ __forceinline__ bool set_has(const DevSet& set, uint64_t k) { return set_hit(set_probe(set, k), k); }
+
 // ------------------------------------------------------------------------- partitioned matrix
 // TTRowPartitionedMatrix_Row, mcmc/partitioned-alloc.h:22-29, with 64-bit offsets.
 

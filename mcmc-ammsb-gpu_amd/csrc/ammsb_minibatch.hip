@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // table slot hash (mur
 }
 
 __device__ __forceinline__ void mb_draw_one(ammsb_seed* seeds, const MbWork& w, uint32_t j, uint32_t u, uint32_t N,
-                                            const ammsb_set& training, const ammsb_set& heldout, int has_heldout) {
+                                            const DevSet& training, const DevSet& heldout, int has_heldout) {
   ammsb_seed s = seeds[j];
   const uint32_t v = (uint32_t)fast_mod(rng_next(s), fast_mod_init(N));
   seeds[j] = s;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void mb_draw_one(ammsb_seed* seeds, const MbWork& w, 
 }
 
 __global__ __launch_bounds__(MB_BLOCK) void mb_draw_kernel(ammsb_seed* seeds, MbWork w, uint32_t u, uint32_t N,
-                                                            ammsb_set training, ammsb_set heldout, int has_heldout) {
+                                                            DevSet training, DevSet heldout, int has_heldout) {
   const uint32_t j = blockIdx.x * MB_BLOCK + threadIdx.x;
   if (w.desc) u = w.desc->u;
   if (j >= mb_active(w)) return;
@@ -262,12 +262,12 @@ static int minibatch_nonlink_common(ammsb_ctx* ctx, ammsb_seed* seeds, uint32_t 
   MbWork w = carve(workspace, n_candidates, capacity);
   w.desc = desc;
   const uint32_t nb = n_candidates / MB_BLOCK;
-  ammsb_set none = {nullptr, 1, 0};
+  const ammsb_set none = {nullptr, 1, 0};
   // (tried: draw / count / write / finish as ONE 1024-thread block for capacities <= 4096 candidates, to save three
   // launches per small mini-batch -- 33 us on one CU against 16 us + three boundaries for the four kernels: the
   // sampling chain became what bounds a C1 step, 0.0304 -> 0.0362 ms; removed)
-  mb_draw_kernel<<<nb, MB_BLOCK, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, *training_set,
-                                         heldout_set ? *heldout_set : none, heldout_set ? 1 : 0);
+  mb_draw_kernel<<<nb, MB_BLOCK, 0, s>>>(seeds, w, u, (uint32_t)ctx->params.N, dev_set(*training_set),
+                                         dev_set(heldout_set ? *heldout_set : none), heldout_set ? 1 : 0);
   mb_count_kernel<<<nb, MB_BLOCK, 0, s>>>(w);
   mb_write_kernel<<<nb, MB_BLOCK, 0, s>>>(w, u, m, edges_out, nodes_out, count_out);
   mb_finish_kernel<<<64, 256, 0, s>>>(m, count_out, edges_out, nodes_out, w.table, w.H, desc);

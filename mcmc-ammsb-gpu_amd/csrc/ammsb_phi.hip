@@ -26,13 +26,24 @@
 
 using namespace ammsb;
 
+#ifdef AMMSB_PHI_TRACE
+// development aid (tools/phi_trace.sh): shader-clock stamps of block 0's first node, read back with ammsb_debug_trace
+__device__ unsigned long long g_phi_trace[256];
+#define PHI_TRACE(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 256) g_phi_trace[(slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ammsb_debug_trace(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phi_trace), sizeof(unsigned long long) * (n < 256 ? n : 256)) == hipSuccess ? 0 : -2;
+}
+#else
+#define PHI_TRACE(slot) do { } while (0)
+#endif
+
 namespace {
 
 struct PhiArgs {
   const float* beta;
   ammsb_rpm pi;
   const float* phi_sum;
-  ammsb_set set;
+  DevSet set;  // (ammsb_dev.h: the descriptor + the modulo magic)
   const uint32_t* nodes;
   const uint32_t* neighbors;
   ammsb_seed* seeds;
@@ -695,6 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
   };
 
+  PHI_TRACE(0);
   for (uint64_t i = g; i < st.n_nodes; i += st.G) {
     const uint32_t node = a.nodes[i];
     __syncthreads();  // orders the LDS traffic of consecutive nodes
@@ -702,6 +714,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
     // the same neighbours (another dependent round trip) fly together with those rows instead of ahead of them
     for (uint32_t q = tid; q < n; q += L) s_nb[q] = a.neighbors[i * n + q];
     __syncthreads();
+    PHI_TRACE(1);
 
     const float phi_sum = a.phi_sum[node];
     const float inv_phi_sum = 1.0f / phi_sum;
@@ -714,11 +727,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
 #pragma unroll
     for (uint32_t r = 0; r < (uint32_t)(D - U); ++r)
       if (r < n) request(r, r);  // rows 0 .. D-U-1 fly during the per-node set-up
-    for (uint32_t q = tid; q < n; q += L) {
-      const uint32_t nb = s_nb[q];
-      if (set_has(a.set, make_edge(node, nb))) s_nb[q] = nb | 0x80000000u;  // (loads return in order: after the rows above)
+    // The probes' loads are issued here and consumed after the lane's normals have been drawn (REGN: all KV of them):
+    // the ziggurat -- ~1000 cycles a draw for a wave, measured with in-kernel stamps (tools/phi_trace.sh) -- used to
+    // sit in the first row iteration, behind rows that had long landed; now it runs under the probes' round trip.
+    // (n <= 64 here: one probe per lane at most, the loop form is kept for the general case below)
+    const bool one_probe = n <= (uint32_t)L;
+    const uint32_t my_nb = one_probe && (uint32_t)tid < n ? s_nb[tid] : 0u;
+    SetProbe my_probe = {};
+    if (one_probe && (uint32_t)tid < n) my_probe = set_probe(a.set, make_edge(node, my_nb));
+    float zraw[REGN ? KV : 1];
+    if constexpr (REGN) {
+      if (a.noise_on) {
+#pragma unroll
+        for (int j = 0; j < KV; ++j) zraw[j] = rng_normal(rs, &zig);
+      }
+    }
+    if (one_probe) {
+      if ((uint32_t)tid < n && set_hit(my_probe, make_edge(node, my_nb))) s_nb[tid] = my_nb | 0x80000000u;
+    } else {
+      for (uint32_t q = tid; q < n; q += L) {
+        const uint32_t nb = s_nb[q];
+        if (set_has(a.set, make_edge(node, nb))) s_nb[q] = nb | 0x80000000u;  // (loads return in order: after the rows above)
+      }
     }
     __syncthreads();
+    PHI_TRACE(2);
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
       grads[p] = f32x2{0.0f, 0.0f};
@@ -735,12 +768,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       }
     }
 
+    PHI_TRACE(3);
     for (uint32_t q = 0; q < n; q += U) {  // n is a multiple of U (dispatch)
       float* row[U];
 #pragma unroll
       for (int r = 0; r < U; ++r) row[r] = ring + ((q + r) & (D - 1)) * KW;
       // every LDS read of rows q-U .. q-1 has been consumed; their slots take rows q+D-U .. q+D-1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PHI_TRACE(8 + 4 * (q / U));
       if (q + (D - U) < n) {  // n a multiple of U: all U rows exist
 #pragma unroll
         for (int r = 0; r < U; ++r) request(q + (D - U) + r, (q + (D - U) + r) & (D - 1));
@@ -748,12 +783,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       // U of the lane's KPT normals per iteration, drawn while the rows are on their way (ascending column order)
       if (a.noise_on) {
         if constexpr (REGN) {
-          if (q == 0) {
+          if (q == 0) {  // (drawn in the prologue, under the probes' latency; stream order = ascending j as before)
 #pragma unroll
-            for (int j = 0; j < KV; ++j) {
-              const float z = rng_normal(rs, &zig);
-              if (VLn::keeps(tid, (uint32_t)j)) nz[j / VLn::PER] = nz[j / VLn::PER] * z;
-            }
+            for (int j = 0; j < KV; ++j)
+              if (VLn::keeps(tid, (uint32_t)j)) nz[j / VLn::PER] = nz[j / VLn::PER] * zraw[j];
           }
         } else {
 #pragma unroll
@@ -772,6 +805,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
         else if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      PHI_TRACE(8 + 4 * (q / U) + 1);
       float ee[U], sg[U], part[U], lo[U], psum[U];
       f32x2 prr[REGP ? U : 1][REGP ? HP : 1];
       bool fast[U], all_fast = true;
@@ -874,6 +908,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       }
     }
 
+    PHI_TRACE(4);
     // normals the loop did not get to (n < KPT): one rolled loop, a single copy of the ziggurat code
     if constexpr (!REGN) {  // (REGN: n >= U == KPT, the first row group drew them all)
       if (a.noise_on) {
@@ -905,6 +940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + tid + 2 * L * p);
       __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
     }
+    PHI_TRACE(5);
   }
   if (a.noise_on && tid < VL) a.seeds[(uint64_t)g * VL + tid] = rs;
 }
@@ -1720,7 +1756,7 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   a.beta = beta;
   a.pi = *pi;
   a.phi_sum = phi_sum;
-  a.set = *training_set;
+  a.set = dev_set(*training_set);
   a.nodes = nodes;
   a.neighbors = neighbors;
   a.seeds = seeds;

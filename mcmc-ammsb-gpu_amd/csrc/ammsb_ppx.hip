@@ -21,7 +21,7 @@ namespace {
 struct PpxArgs {
   const float* beta;
   ammsb_rpm pi;
-  ammsb_set set;
+  DevSet set;  // (ammsb_dev.h: the descriptor + the modulo magic)
   const uint64_t* edges;
   float* ppx_per_edge;
   double* ll_partials;               // [P, 2]
@@ -508,7 +508,7 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
   PpxArgs a;
   a.beta = beta;
   a.pi = *pi;
-  a.set = *heldout_set;
+  a.set = dev_set(*heldout_set);
   a.edges = edges;
   a.ppx_per_edge = ppx_per_edge;
   a.ll_partials = ctx->ppx_partials;
