@@ -21,6 +21,18 @@
 
 using namespace ammsb;
 
+#ifdef AMMSB_BETA_TRACE
+// development aid (tools/beta_trace.sh): shader-clock stamps of slot 0 of beta_grads_lds_kernel, read back with
+// ammsb_debug_trace_beta
+__device__ unsigned long long g_beta_trace[256];
+#define BETA_TRACE(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 256) g_beta_trace[(slot)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int ammsb_debug_trace_beta(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_beta_trace), sizeof(unsigned long long) * (n < 256 ? n : 256)) == hipSuccess ? 0 : -2;
+}
+#else
+#define BETA_TRACE(slot) do { } while (0)
+#endif
+
 namespace {
 
 struct BetaArgs {
@@ -306,6 +318,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   const uint32_t gs = blockIdx.x;  // partial-row slot; the grid is exactly P blocks (at least P with a descriptor)
   if (gs >= st.P) return;          // block-uniform
   const float EPS = a.epsilon;
+  BETA_TRACE(0);
 
   f32x2 bk[HP], d0n[HP], d1l[HP], noo[HP];
 #pragma unroll
@@ -349,7 +362,10 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   };
   uint32_t tb = 0;
   unsigned long long ym = 0, ym_next = 0;
-  unsigned long long kv = load_keys(0, &ym), kv_next = load_keys(64, &ym_next);
+  BETA_TRACE(1);
+  unsigned long long kv = load_keys(0, &ym), kv_next = 0;
+  if (trips > 64u) kv_next = load_keys(64, &ym_next);  // (block-uniform; a slot of at most 64 edges never looks there)
+  BETA_TRACE(2);
 
   auto key_of = [&](uint32_t t, bool* y) -> unsigned long long {
     const uint32_t rel = t - tb;  // 0 .. 127 by construction
@@ -433,9 +449,11 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   }
 
   for (uint32_t t = 0; t < D - 1 && t < trips; ++t) request(t);
+  BETA_TRACE(3);
   for (uint32_t t = 0; t < trips; ++t) {
     float* row_b = ring + (t % D) * KW;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot (t - 1) % D has been read for the last time
+    BETA_TRACE(8 + 4 * t);
     if (t + D - 1 < trips) {
       if (t + D - 1 >= tb + 128) {  // the look-ahead leaves the two key windows: slide them (t >= tb + 64 here)
         kv = kv_next;
@@ -461,6 +479,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
+    BETA_TRACE(8 + 4 * t + 1);
     bool y;
     const unsigned long long edge = key_of(t, &y);
     y = __builtin_amdgcn_readfirstlane((int)y) != 0;
@@ -494,7 +513,10 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     }
 
     // CALC_PROBS, beta.cc:145-160
+    // (probs[] stays in registers between the two passes: the write-back into the ring slot and its re-read cost a
+    // wave ~15 % of a trip -- in-kernel stamps, tools/beta_trace.sh -- and 16 registers do not change the occupancy)
     float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
+    f32x2 prr[HP];
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
       f32x2 pb;
@@ -504,15 +526,16 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       VLn::chain(scratch, f.x);
       VLn::chain(scratch, f.y);
       const f32x2 pr = (y ? bk[p] : 1.0f - bk[p]) * f;
-      row_b[ln + 128 * p] = pr.x;
-      row_b[ln + 128 * p + 64] = pr.y;
+      prr[p] = pr;
       VLn::chain(ppart, pr.x);
       VLn::chain(ppart, pr.y);
       const float m0 = fabsf(pr.x), m1 = fabsf(pr.y);
       lo = fminf(fminf(lo, m0 == 0.0f ? 1.0f : m0), m1 == 0.0f ? 1.0f : m1);  // an exact zero divides exactly
     }
     float pi_sum = scratch, probs_sum = ppart;
+    BETA_TRACE(8 + 4 * t + 2);
     group_sum2(pi_sum, probs_sum);  // beta.cc:209-217
+    BETA_TRACE(8 + 4 * t + 3);
     const float w = y ? EPS : (1.0f - EPS);
     const float prob_0 = w * (1.0f - pi_sum);
     probs_sum += prob_0;
@@ -523,21 +546,21 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
-        const f32x2 pr = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
-        const f32x2 f = div_exact3(pr, psum2, rps2);
+        const f32x2 f = div_exact3(prr[p], psum2, rps2);
         acc0[p] += f * (y ? noo[p] : d0n[p]);
         acc1[p] += f * (y ? d1l[p] : noo[p]);
       }
     } else {
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
-        const f32x2 f = f32x2{row_b[ln + 128 * p] / probs_sum, row_b[ln + 128 * p + 64] / probs_sum};
+        const f32x2 f = f32x2{prr[p].x / probs_sum, prr[p].y / probs_sum};
         acc0[p] += f * (y ? noo[p] : d0n[p]);
         acc1[p] += f * (y ? d1l[p] : noo[p]);
       }
     }
   }
 
+  BETA_TRACE(4);
   float* out = a.partials + (uint64_t)gs * 2 * K;
 #pragma unroll
   for (int p = 0; p < HP; ++p) {

@@ -1,0 +1,60 @@
+#!/bin/bash
+# In-kernel shader-clock stamps of beta_grads_lds_kernel (slot 0): where a wave's time goes.
+# Build (CPU box): tools/beta_trace.sh build; run (GPU box): tools/beta_trace.sh run K edges
+set -e
+cd "$(dirname "$0")/.."
+if [ "$1" = build ]; then
+  mkdir -p tools/ab/btrace
+  for f in core phi beta ppx minibatch loop setbuild; do
+    extra=""; [ $f = beta ] && extra="-DAMMSB_BETA_TRACE"
+    if [ $f = beta ] || [ ! -f tools/ab/btrace/ammsb_$f.o ] || [ mcmc-ammsb-gpu_amd/csrc/ammsb_$f.hip -nt tools/ab/btrace/ammsb_$f.o ] || [ mcmc-ammsb-gpu_amd/csrc/ammsb_dev.h -nt tools/ab/btrace/ammsb_$f.o ]; then
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $extra \
+        -c mcmc-ammsb-gpu_amd/csrc/ammsb_$f.hip -o tools/ab/btrace/ammsb_$f.o &
+    fi
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/btrace/libammsb_hip_btrace.so tools/ab/btrace/ammsb_*.o -lpthread
+  exit 0
+fi
+shift
+AMMSB_HIP_LIB=$PWD/tools/ab/btrace/libammsb_hip_btrace.so python - "$@" <<'PY'
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.getcwd()
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch, ammsb_pkg
+ammsb_pkg.load()
+from mcmc_ammsb_gpu_amd import ops as hip
+import oracle_lib as orc
+orc.build()
+from test_gpu_parity import Problem
+K, ne = [int(x) for x in sys.argv[1:3]]
+N = max(2 * ne, 20000)
+pr = Problem(orc, hip, N, K, 8, 16, deg=8)
+rng = np.random.default_rng(1)
+u = int(rng.integers(0, N))
+vs = rng.permutation(N)[:ne].astype(np.uint64)
+mbe = orc.make_edge(np.full(ne, u, dtype=np.uint64), vs)   # a node-stratified mini-batch: one shared end point
+upd = hip.BetaUpdater(pr.ctx, pr.theta, pr.beta, pr.pi, pr.dset, (44, 45), 64)
+dev = pr.ctx.from_numpy(mbe)
+lib = pr.ctx.lib
+lib.ammsb_debug_trace_beta.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+for rep in range(3):
+    upd.count_calls += 1
+    upd.calculate_grads(dev, mbe.size)
+    torch.cuda.synchronize()
+buf = (C.c_ulonglong * 256)()
+assert lib.ammsb_debug_trace_beta(buf, 256) == 0
+t = np.array(buf[:], dtype=np.int64)
+print(pr.ctx.kernel_names()["beta_grads"], "edges", ne)
+print("constants (theta reciprocals)  +%6d" % (t[1] - t[0]))
+print("two key windows loaded+probed  +%6d" % (t[2] - t[1]))
+print("first requests issued          +%6d" % (t[3] - t[2]))
+prev = t[3]
+trips = int((t[8:248:4] > 0).sum())
+for k in range(min(trips, 12)):
+    a, b, c, d = t[8 + 4 * k: 12 + 4 * k]
+    print("  trip %2d: lgkm +%5d | request+row landed +%5d | probs pass +%5d | two WG_SUMs +%5d" % (k, a - prev, b - a, c - b, d - c))
+    prev = d
+print("trips", trips, "loop total", t[4] - t[3], "per trip", (t[4] - t[3]) // max(trips, 1), "| whole wave", t[4] - t[0])
+PY
