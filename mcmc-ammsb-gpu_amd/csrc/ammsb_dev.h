@@ -428,7 +428,18 @@ __device__ __forceinline__ void vgroup_sum(const float* const (&vals)[N], uint32
     const float* v = vals[0];
 #pragma unroll
     for (int i = 1; i < N; ++i) v = which == (uint32_t)i ? vals[i] : v;
-    for (uint32_t k = vl; k < K; k += L) s += v[k];
+    // the adds are the reference's chain (sequential by definition); the LDS reads feeding it are independent and are
+    // issued eight at a time -- one read per add at LDS latency made this loop the whole run time of the generic
+    // kernels (K = 4096 at wg 32: 128 dependent round trips per row)
+    uint32_t k = vl;
+    for (; k + 7 * L < K; k += 8 * L) {
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = v[k + i * L];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += x[i];
+    }
+    for (; k < K; k += L) s += v[k];
   }
   float* r = res + phase * N;
   phase ^= 1;

@@ -1486,22 +1486,47 @@ int launch_pi(ammsb_ctx* ctx, const ammsb_rpm& pi, float* phi_sum, const float* 
 // (ammsb_dev.h) for the sum, and for the noise thread l < L owns stream g L + l and draws for columns l, l + L, ...
 // in ascending order (phi.cc:266-274, 291, 300).  Same operations in the same order on every value as
 // update_phi_kernel<L, KPT>: bit-identical to it (and to the oracle) wherever both run.
-template <int CPT>
-__global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, uint32_t L, uint32_t lgL) {
-  extern __shared__ __align__(16) char smem[];  // [K] probs / noise, [L] lane partials, [2] sums, [n] u32
+// The noise.  Stream g L + l draws the normals of columns l, l + L, ... of group g's nodes one after the other
+// (phi.cc:266-274): K / L sequential ziggurat draws per node and lane -- 128 at K = 4096, wg 32, about 1000 cycles each
+// for a wave, on 32 of a block's 512 threads: more than half of a node's time when drawn inside update_phi_gen_kernel
+// (C5-sized launch: 27 ms of which ~15 ms draws).  But the draws depend on nothing except the stream: phi_noise_kernel
+// makes them first, ONE THREAD PER STREAM over the whole launch (2 M streams side by side), into the phi_vec rows the
+// update is about to overwrite; update_phi_gen_kernel reads its noise from there.  Same streams, same order.
+__global__ __launch_bounds__(256) void phi_noise_kernel(const PhiArgs a, uint32_t L, uint32_t lgL) {
   __shared__ ZigTables zig;
+  const PhiStep st = phi_step(a);
+  if (st.n_nodes == 0) return;  // (uniform) a skipped step
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
+  zig_load(&zig);
+  __syncthreads();
+  const uint64_t sid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // stream within the launch's group range
+  const uint32_t g = a.group_begin + (uint32_t)(sid >> lgL), l = (uint32_t)sid & (L - 1);
+  if (g >= st.group_end) return;
+  ammsb_seed rs = a.seeds[(uint64_t)g * L + l];
+  for (uint64_t i = g; i < st.n_nodes; i += st.G) {
+    float* out = a.phi_vec + i * a.K;
+    for (uint32_t k = l; k < a.K; k += L) out[k] = rng_normal(rs, &zig);
+  }
+  a.seeds[(uint64_t)g * L + l] = rs;
+}
+
+// U neighbour rows go through one barrier phase together (n % U == 0, U * L <= blockDim.x): their U WG_SUM chains
+// run side by side on U * L threads (vgroup_sum<U>) -- at L = 32 a lone chain leaves 15 of a block's 16 waves idle
+// for 128 dependent adds per row.
+template <int CPT, int U>
+__global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, uint32_t L, uint32_t lgL) {
+  extern __shared__ __align__(16) char smem[];  // [U][K] probs, [U L] lane partials, [2 U] sums, [n] u32
   const uint32_t K = a.K, n = a.n, T = blockDim.x, t = threadIdx.x;
   float* s_vals = reinterpret_cast<float*>(smem);
-  float* s_aux = s_vals + K;
-  float* s_res = s_aux + L;
-  uint32_t* s_nb = reinterpret_cast<uint32_t*>(s_res + 2);
+  float* s_aux = s_vals + (size_t)U * K;
+  float* s_res = s_aux + U * L;
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(s_res + 2 * U);
 
   const PhiStep st = phi_step(a);
-  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
+  if (!a.noise_on) note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);  // (with noise the step starts in phi_noise_kernel)
   const uint32_t g = a.group_begin + blockIdx.x;
   if (g >= st.group_end) return;  // block-uniform
   const float EPS = a.epsilon;
-  if (a.noise_on) zig_load(&zig);
 
   auto col = [&](int j) -> uint32_t { return t + (uint32_t)j * T; };
   auto ccol = [&](int j) -> uint32_t {
@@ -1518,9 +1543,6 @@ __global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, ui
     bf[j] = b - EPS;
     beta_safe = beta_safe && in_range(b, EPS, kBetaHi);
   }
-  ammsb_seed rs = {0, 0};
-  if (a.noise_on && t < L) rs = a.seeds[(uint64_t)g * L + t];  // rand->base_[GET_GLOBAL_ID()], phi.cc:291
-
   int phase = 0;
   for (uint64_t i = g; i < st.n_nodes; i += st.G) {
     const uint32_t node = a.nodes[i];
@@ -1535,7 +1557,8 @@ __global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, ui
     const float phi_sum = a.phi_sum[node];
     const float inv_phi_sum = 1.0f / phi_sum;
     const float* row_a = rpm_row(a.pi, node);
-    float pi_a[CPT], grads[CPT], rden[CPT];
+    float* out = a.phi_vec + i * K;
+    float pi_a[CPT], grads[CPT], rden[CPT], noise[CPT];
     bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
@@ -1545,69 +1568,82 @@ __global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, ui
       const float den = pi_a[j] * phi_sum;
       rden[j] = exact_rcp(den);
       node_safe = node_safe && (in_range(den, kDenLo, kDenHi) || !has(j));
+      noise[j] = a.noise_on ? out[ccol(j)] : 1.0f;  // the column's normal, left there by phi_noise_kernel
     }
 
-    float cur[CPT], nxt[CPT];
-    auto load_row = [&](float (&dst)[CPT], uint32_t q) {
-      const uint32_t w = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
-      const float* row = rpm_row(a.pi, w);
+    float cur[U][CPT], nxt[U][CPT];
+    auto load_rows = [&](float (&dst)[U][CPT], uint32_t q0) {
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) dst[j] = row[ccol(j)];
+      for (int r = 0; r < U; ++r) {
+        const uint32_t q = q0 + r < n ? q0 + r : n - 1;  // unconditional: past the end re-requests the last row
+        const uint32_t w = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
+        const float* row = rpm_row(a.pi, w);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) dst[r][j] = row[ccol(j)];
+      }
     };
-    if (n > 0) load_row(cur, 0);
-    for (uint32_t q = 0; q < n; ++q) {
-      load_row(nxt, q + 1 < n ? q + 1 : q);  // unconditional: the last trip re-requests its own row
-      const bool y = __builtin_amdgcn_readfirstlane(s_nb[q] >> 31) != 0;
-      const float e = y ? EPS : 1.0f - EPS;
-      float pr[CPT];
-      float lo = 1.0f;
+    if (n > 0) load_rows(cur, 0);
+    for (uint32_t q = 0; q < n; q += U) {  // n is a multiple of U (dispatch)
+      load_rows(nxt, q + U);
+      float pr[U][CPT], lo[U];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {  // phi.cc:241-253
-        const float tt0 = cur[j] * bf[j];
-        const float tt = y ? tt0 + e : e - tt0;
-        pr[j] = pi_a[j] * tt;
-        if (has(j)) s_vals[col(j)] = pr[j];
-        lo = fminf(lo, has(j) ? fabsf(pr[j]) : 1.0f);
+      for (int r = 0; r < U; ++r) {
+        const bool y = __builtin_amdgcn_readfirstlane(s_nb[q + r] >> 31) != 0;
+        const float e = y ? EPS : 1.0f - EPS;
+        lo[r] = 1.0f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {  // phi.cc:241-253
+          const float tt0 = cur[r][j] * bf[j];
+          const float tt = y ? tt0 + e : e - tt0;
+          pr[r][j] = pi_a[j] * tt;
+          if (has(j)) s_vals[(size_t)r * K + col(j)] = pr[r][j];
+          lo[r] = fminf(lo[r], has(j) ? fabsf(pr[r][j]) : 1.0f);
+        }
       }
       __syncthreads();
-      const float* const vv[1] = {s_vals};
-      float sums[1];
-      vgroup_sum<1>(vv, K, L, lgL, s_aux, s_res, phase, sums);  // phi.cc:254-257
-      const float probs_sum = sums[0];
-      // phi.cc:259-263: grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
-      if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
-        const float rps = exact_rcp(probs_sum);
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          float qv = div_exact3(pr[j], probs_sum, rps);
-          qv = div_exact3(qv, pi_a[j] * phi_sum, rden[j]);
-          grads[j] += qv - inv_phi_sum;
-        }
+      float sums[U];
+      if constexpr (U == 1) {
+        const float* const vv[1] = {s_vals};
+        vgroup_sum<1>(vv, K, L, lgL, s_aux, s_res, phase, sums);  // phi.cc:254-257
+      } else if constexpr (U == 2) {
+        const float* const vv[2] = {s_vals, s_vals + K};
+        vgroup_sum<2>(vv, K, L, lgL, s_aux, s_res, phase, sums);
       } else {
+        const float* const vv[4] = {s_vals, s_vals + K, s_vals + 2 * (size_t)K, s_vals + 3 * (size_t)K};
+        vgroup_sum<4>(vv, K, L, lgL, s_aux, s_res, phase, sums);
+      }
+      // phi.cc:259-263, rows in order: grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          float qv = pr[j] / probs_sum;
-          qv = qv / (pi_a[j] * phi_sum);
-          grads[j] += qv - inv_phi_sum;
+      for (int r = 0; r < U; ++r) {
+        const float probs_sum = sums[r];
+        if (node_safe && lo[r] >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+          const float rps = exact_rcp(probs_sum);
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) {
+            float qv = div_exact3(pr[r][j], probs_sum, rps);
+            qv = div_exact3(qv, pi_a[j] * phi_sum, rden[j]);
+            grads[j] += qv - inv_phi_sum;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) {
+            float qv = pr[r][j] / probs_sum;
+            qv = qv / (pi_a[j] * phi_sum);
+            grads[j] += qv - inv_phi_sum;
+          }
         }
       }
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) cur[j] = nxt[j];
+      for (int r = 0; r < U; ++r)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) cur[r][j] = nxt[r][j];
     }
 
-    // the noise of column k comes from stream g L + (k mod L), drawn in ascending k (phi.cc:266-274)
-    if (a.noise_on) {
-      if (t < L)
-        for (uint32_t k = t; k < K; k += L) s_vals[k] = rng_normal(rs, &zig);
-      __syncthreads();
-    }
     // SGLD step, phi.cc:265-274
-    float* out = a.phi_vec + i * K;
     const float half = st.eps_t / 2;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       if (has(j)) {
-        const float noise = a.noise_on ? s_vals[col(j)] : 1.0f;
         const float phi_k = pi_a[j] * phi_sum;
         const float ng = a.Nn * grads[j];
         float in = a.alpha - phi_k;
@@ -1616,13 +1652,12 @@ __global__ __launch_bounds__(512) void update_phi_gen_kernel(const PhiArgs a, ui
         const float aa = phi_k + drift;
         const float ep = st.eps_t * phi_k;
         const float sq = sqrtf(ep);
-        const float bb = sq * noise;
+        const float bb = sq * noise[j];
         const float v = fabsf(aa + bb);
         out[col(j)] = v > 1e-24f ? v : 1e-24f;
       }
     }
   }
-  if (a.noise_on && t < L) a.seeds[(uint64_t)g * L + t] = rs;
 }
 
 // update_pi for the same shapes (phi.cc:177-197): one block per node, elementwise over all threads, WG_SUM emulated
@@ -1680,15 +1715,37 @@ inline uint32_t gen_threads(uint64_t K, uint32_t L, uint32_t sums) {
   return T <= 512 ? T : 0;
 }
 
+template <int CPT, int U>
+int launch_phi_gen_u(ammsb_ctx* ctx, const PhiArgs& a, uint32_t wg, uint32_t T, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)U * a.K + U * wg + 2 * U) + sizeof(uint32_t) * a.n;
+  static const bool big = [] {  // (more than the default 64 KiB of dynamic LDS at K = 8192 with several rows per phase)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(update_phi_gen_kernel<CPT, U>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) == hipSuccess;
+  }();
+  (void)big;
+  static const std::string name = ammsb_kname("update_phi_gen_kernel<%d, %d>", CPT, U);
+  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
+  if (a.noise_on) {  // the launch's normals first, one thread per stream (see phi_noise_kernel)
+    const uint64_t streams = (uint64_t)n_groups * wg;
+    phi_noise_kernel<<<(unsigned)((streams + 255) / 256), 256, 0, s>>>(a, wg, ilog2_u32(wg));
+    AMMSB_LAUNCH_CHECK(ctx);
+  }
+  update_phi_gen_kernel<CPT, U><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 int launch_phi_gen(ammsb_ctx* ctx, const PhiArgs& a, uint32_t wg, uint32_t n_groups, hipStream_t s) {
   const uint32_t T = gen_threads(a.K, wg, 1);
   if (!T) return AMMSB_ERANGE;
-  const size_t lds = sizeof(float) * ((size_t)a.K + wg + 2) + sizeof(uint32_t) * a.n;
-  ctx->kernel_name[AMMSB_KN_PHI] = gen_cpt(a.K) == 8 ? "update_phi_gen_kernel<8>" : "update_phi_gen_kernel<16>";
-  if (gen_cpt(a.K) == 8) update_phi_gen_kernel<8><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
-  else update_phi_gen_kernel<16><<<n_groups, T, lds, s>>>(a, wg, ilog2_u32(wg));
-  AMMSB_LAUNCH_CHECK(ctx);
-  return AMMSB_OK;
+  // rows per barrier phase: as many WG_SUM chains side by side as the block has threads for (and n divides into)
+  const uint32_t u = (a.n % 4 == 0 && 4 * wg <= T) ? 4 : (a.n % 2 == 0 && 2 * wg <= T) ? 2 : 1;
+  if (gen_cpt(a.K) == 8) {
+    if (u == 4) return launch_phi_gen_u<8, 4>(ctx, a, wg, T, n_groups, s);
+    if (u == 2) return launch_phi_gen_u<8, 2>(ctx, a, wg, T, n_groups, s);
+    return launch_phi_gen_u<8, 1>(ctx, a, wg, T, n_groups, s);
+  }
+  return launch_phi_gen_u<16, 1>(ctx, a, wg, T, n_groups, s);  // (16 columns per thread leave no registers for a second row)
 }
 
 // smallest instantiated KPT >= ceil(K / L), or 0 if K is too long for this work-group size

@@ -280,6 +280,26 @@ def test_c5_full_size(env, orc):
     assert torch.equal(phi.phi_vec[:nv], full) and torch.equal(phi.rand.seeds, seeds_after)
     del full
 
+    # ---- the same launch at the reference's DEFAULT work-group size (32, main.cc:61): 128 columns per work-item at
+    #      K = 4096 -- update_phi_gen_kernel at full C5 size (round 2 refused this shape), against the oracle at L = 32
+    phi32 = ops.PhiUpdater(ctx, lrn.beta, pi, phi_sum, lrn.trainingSet, nv, (42, 43), 32)
+    phi32.count_calls = 1
+    phi32.update_phi(s.dev_nodes, nbrs, nv)
+    torch.cuda.synchronize()
+    assert "gen_kernel" in ctx.kernel_names()["update_phi"]
+    got32 = phi32.phi_vec[:nv]
+    assert bool(torch.isfinite(got32).all()) and float(got32.min()) >= 1e-24
+    for i in pick[:40]:
+        g = int(i % G)
+        chain = [g] if i < G else [g, int(i)]
+        seeds = orc.rng_init(32, 42 + g * 32, 43 + g * 32)
+        for idx in chain:
+            want = orc.update_phi(po, beta_h, sub_pi.reshape(-1), sub_ps, oset, remap(nodes_h[idx:idx + 1]),
+                                  remap(nbrs_h[idx]), 1, seeds, 32, 1, True)
+        assert np.array_equal(_bits(got32[int(i)].cpu().numpy()), _bits(want[0])), "wg 32, node index %d" % i
+    del phi32, got32
+    torch.cuda.empty_cache()
+
     # ---- update_pi: rows normalised in WG_SUM order, phi_sum = row sum, everything else untouched
     phi.update_pi(s.dev_nodes, nv)
     torch.cuda.synchronize()

@@ -38,7 +38,8 @@ def bits(a):
 for N, K, n, n_nodes, L in [(2048, 64, 8, 300, 64), (2048, 64, 8, 300, 32), (2048, 256, 32, 100, 64),
                             (2048, 256, 32, 100, 128), (2048, 256, 7, 100, 256), (1024, 1000, 5, 64, 64),
                             (1024, 1024, 32, 40, 64), (1024, 1024, 32, 40, 256), (512, 2048, 8, 20, 128),
-                            (512, 2048, 8, 20, 512), (600, 100, 6, 50, 16)]:
+                            (512, 2048, 8, 20, 512), (600, 100, 6, 50, 16),
+                            (70000, 64, 4, 65535 + 700, 32)]:   # groups with a second node: the noise pre-pass walks both
     for noise in (False, True):
         pr = Problem(orc, hip, N, K, n, n_nodes)
         upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L,
