@@ -114,6 +114,55 @@ def test_world2_matches_single_process(tmp_path, case, chunks, rep):
     assert np.allclose(r1["ppx_state"][per:], one["ppx_state"][per:], rtol=1e-4)
 
 
+@pytest.mark.parametrize("case,chunks,rep", [
+    ((150000, 32, 70000, 2, 2), 2, 0.12),    # C4's rank count and its expected split: 12 % of the groups replicated
+    ((3000, 32, 256, 8, 4), 1, 0.0),         # small batches: every launch fits rank 0's block (broadcast path), 7 idle owners
+], ids=["c4-shape-split", "small"])
+def test_world8_matches_single_process(tmp_path, case, chunks, rep):
+    """BASELINE's C4 shards over EIGHT ranks; no 8-GPU node is available to the builder, so the rank arithmetic of that
+    world size (block ownership, in-place all-gather regions that reach past row G, tail rows parked by eight owners,
+    rank-ordered gradient sum, eight perplexity slices) is rehearsed here over gloo with the oracle-backed operators."""
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    out = str(tmp_path)
+    W = 8
+    _run(0, 1, 0, out, case)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run, args=(r, W, port, out, case, chunks, rep)) for r in range(W)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    rs = [np.load(os.path.join(out, "w%d_r%d.npz" % (W, r))) for r in range(W)]
+    for r in rs[1:]:   # replicas stay identical
+        for k in ("pi", "phi", "theta", "beta", "ppx", "edges", "split"):
+            assert np.array_equal(rs[0][k], r[k]), k
+    assert np.array_equal(rs[0]["pi1"], one["pi1"])          # first iteration: independent of the split
+    assert rs[0]["edges"][0] == one["edges"][0] and rs[0]["ppx"][0] == one["ppx"][0]
+    assert np.allclose(rs[0]["theta"], one["theta"], rtol=5e-5, atol=1e-7)
+    assert np.allclose(rs[0]["pi"], one["pi"], rtol=1e-3, atol=1e-7)
+    assert abs(rs[0]["ppx"][1] - one["ppx"][1]) <= 2e-5 * one["ppx"][1]
+    L = 32
+    g_rep, cc = (int(x) for x in rs[0]["split"])
+    s = one["seeds"].reshape(-1, 2)
+    lim = min(s.shape[0], 65535 * L)
+    g = np.arange(lim) // L
+    owner = np.where(g < g_rep, -1, ((g - g_rep) // cc) % W)   # -1: replicated, advanced by every rank
+    for r in range(W):
+        sr = rs[r]["seeds"].reshape(-1, 2)
+        mine = (owner == r) | (owner == -1)
+        assert np.array_equal(sr[:lim][mine], s[:lim][mine]), "rank %d's own streams" % r
+    H = one["ppx_state"].size
+    per = (H + W - 1) // W
+    for r in range(W):
+        lo, hi = min(r * per, H), min((r + 1) * per, H)
+        assert np.allclose(rs[r]["ppx_state"][lo:hi], one["ppx_state"][lo:hi], rtol=1e-4)
+
+
 def _run_ckpt(rank, world, port, outdir):
     for p in (ROOT, HERE):
         if p not in sys.path:
