@@ -553,6 +553,22 @@ int submit(ammsb_loop* lp, const ammsb_mb_choice* pending, const ammsb_mb_choice
   LOOP_HIP(lp, hipEventRecord(lp->ev_in, s));
   LOOP_HIP(lp, hipStreamWaitEvent(lp->main, lp->ev_in, 0));
   uint32_t done = done0;
+  if (done0 == n_steps && avail0 <= n_steps) {
+    // (resumption only) every step of the run has completed, but the mini-batch it leaves pending was never sampled:
+    // its sampler chain was the one that gave up.  Sample it now, straight from a one-entry descriptor upload.
+    Stage& st = lp->stage[lp->next_stage];
+    lp->next_stage ^= 1;
+    if (st.used) LOOP_HIP(lp, hipEventSynchronize(st.done));
+    st.ring[0] = make_desc(lp, choice(n_steps), first_step_count + n_steps);
+    LOOP_HIP(lp, hipMemcpyAsync(lp->d_ring, st.ring, sizeof(ammsb_step_desc), hipMemcpyHostToDevice, lp->main));
+    LOOP_HIP(lp, hipEventRecord(st.done, lp->main));
+    st.used = true;
+    LOOP_HIP(lp, hipEventRecord(lp->ev_prime, lp->main));
+    LOOP_HIP(lp, hipStreamWaitEvent(lp->side, lp->ev_prime, 0));
+    LOOP_RC(record_sampler(lp, choice(n_steps).link ? 1 : 0, (int)((p0 + n_steps) % NBUF), (int)((p0 + n_steps) & 1u),
+                           lp->d_ring, lp->side));
+    if (ev) LOOP_HIP(lp, hipEventRecord(n_steps == 1 ? lp->ev_first : lp->ev_samp[(n_steps - 2) % NBUF], lp->side));
+  }
   while (done < n_steps) {
     const uint32_t cnt = n_steps - done < CHUNK ? n_steps - done : CHUNK;
     const clk::time_point t_pro = clk::now();
@@ -777,14 +793,18 @@ extern "C" int ammsb_loop_check(ammsb_loop* lp, uint32_t* wait_timeouts) {
   LOOP_HIP(lp, hipMemcpy(lp->d_hs + HS_TIMEOUTS, &clear, sizeof clear, hipMemcpyHostToDevice));
   std::vector<ammsb_loop::Run> runs;
   runs.swap(*lp->runs);
+  // lifetime mini-batches [0, avail_total) have been sampled; a run is complete when its steps have run AND the
+  // mini-batch it leaves pending (lifetime index main_start + n_steps) is among them
+  const uint64_t avail_total = done_total + (avail_ahead <= 3 ? avail_ahead : 0);
   bool resumed = false;
   for (const ammsb_loop::Run& r : runs) {
-    if (r.main_start + r.n_steps <= done_total && !resumed) continue;  // completed before the wait gave up
+    if (!resumed && r.main_start + r.n_steps <= done_total && r.main_start + r.n_steps < avail_total) continue;
     uint32_t done0 = 0, avail0 = 1;
     if (!resumed) {
-      done0 = (uint32_t)(done_total - r.main_start);
-      avail0 = done0 + (avail_ahead <= 3 ? avail_ahead : 0);  // (0 ahead: the give-up was the poll for this very step's batch)
-      if (avail0 == 0) avail0 = 1;                            // the run's pending mini-batch is always there
+      done0 = (uint32_t)(done_total > r.main_start ? done_total - r.main_start : 0);
+      if (done0 > r.n_steps) done0 = r.n_steps;
+      avail0 = (uint32_t)(avail_total > r.main_start ? avail_total - r.main_start : 0);
+      if (avail0 == 0) avail0 = 1;  // a run's first mini-batch was the caller's: always there
       resumed = true;
     }
     const int rc = submit(lp, &r.pending, r.next.data(), r.n_steps, r.first_step_count, r.parity, r.stream, done0, avail0);

@@ -60,7 +60,9 @@ def _same(a, b):
 @pytest.mark.parametrize("fail_at,steps,host_chunk", [(2, 40, 512), (3, 40, 512), (9, 40, 512),
                                                       (1030, 1300, 4096),   # one run, second 1024-step descriptor chunk
                                                       (600, 1500, 512),     # three enqueued runs: second poisoned, third skipped
-                                                      (700, 1500, 700)])    # the give-up at the very end of a run
+                                                      (700, 1500, 700),     # the give-up at the very end of a run
+                                                      (701, 1500, 700),     # ... of the run's PENDING mini-batch, a run follows
+                                                      (701, 700, 700)])     # ... and nothing follows: the next Run() needs it
 def test_given_up_wait_is_recovered_bit_identically(env, fail_at, steps, host_chunk):
     hostlib, learner, torch = env
     ds = _dataset(hostlib)
