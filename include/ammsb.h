@@ -317,7 +317,9 @@ int ammsb_loop_timestamps(ammsb_loop* loop, uint32_t first_step, uint32_t n_step
 int ammsb_loop_step_stamps(ammsb_loop* loop, uint32_t first_step, uint32_t n_steps, double* out_ns);
 /* Name of the kernel the last ammsb_update_phi / ammsb_update_pi / ammsb_beta_grads / ammsb_perplexity call on this
  * context dispatched to (which = 0 / 1 / 2 / 3), spelled as the rocprofv3 kernel trace spells it (a substring of the
- * trace's name column); "" before the first call. */
+ * trace's name column); "" before the first call.  update_phi has two slots: launches of at most AMMSB_PHI_WIDE (512)
+ * groups -- link mini-batches -- take a several-waves-per-node kernel, recorded under which = 4; which = 0 is the form
+ * the large launches take. */
 const char* ammsb_last_kernel_name(const ammsb_ctx* ctx, int which);
 
 /* ---- wg_* primitives (test entry points; kernels of algorithm/{sum,normalize,sort}.cc) ---- */

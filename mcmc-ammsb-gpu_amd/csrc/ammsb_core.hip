@@ -29,7 +29,7 @@ extern "C" const char* ammsb_strerror(int code) {
 extern "C" const char* ammsb_last_error(const ammsb_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
 extern "C" const char* ammsb_last_kernel_name(const ammsb_ctx* ctx, int which) {
-  if (!ctx || which < 0 || which > 3 || !ctx->kernel_name[which]) return "";
+  if (!ctx || which < 0 || which > 4 || !ctx->kernel_name[which]) return "";
   return ctx->kernel_name[which];
 }
 

@@ -23,11 +23,11 @@ struct ammsb_ctx {
   uint32_t max_ppx_blocks;
   // name of the kernel the last update_phi / update_pi / beta gradient / perplexity call dispatched to, as the
   // rocprofv3 kernel trace spells it (ammsb_last_kernel_name)
-  const char* kernel_name[4];
+  const char* kernel_name[5];
   char err[256];
 };
 
-enum { AMMSB_KN_PHI = 0, AMMSB_KN_PI = 1, AMMSB_KN_GRADS = 2, AMMSB_KN_PPX = 3 };
+enum { AMMSB_KN_PHI = 0, AMMSB_KN_PI = 1, AMMSB_KN_GRADS = 2, AMMSB_KN_PPX = 3, AMMSB_KN_PHI_SMALL = 4 };
 
 // "kernel<template arguments>" as the demangler prints it; one static string per launcher instantiation
 static inline std::string ammsb_kname(const char* fmt, ...) {

@@ -399,6 +399,61 @@ struct VLane {
       return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
     }
   }
+  // U = 2 or 4 rows at once, transposed: the same additions in the same association (a + b == b + a bit for bit, so
+  // which lane forms a sum does not matter, only which two values it adds), but every instruction works for all U rows.
+  //   VL = 32  the chain of a row alternates between the two physical lanes of a virtual lane, so the one-row form has
+  //            both halves of the wave run the identical chain; here v_permlane32_swap(row r, row r + U/2) hands the
+  //            lower half both values of row r and the upper half both values of row r + U/2: one swap and two adds
+  //            per column pair for TWO rows (one-row form: a copy, a swap and two adds per row).
+  //   tree     level 32 (VL = 64 only) folds rows r and r + U/2 with one swap + one add (result of r in the lower half,
+  //            of r + U/2 in the upper); level 16 folds the two registers of U = 4 into one with v_permlane16_swap
+  //            (16-lane row i then holds row i's partials); the four DPP levels run once for all rows; row i's sum is
+  //            read from lane 16 i (U = 4) or 32 i (U = 2).
+  // acc[] holds U accumulators (VL = 64) or U/2 (VL = 32), zero-initialised by the caller.
+  template <int U>
+  __device__ __forceinline__ static void chain_rows(float (&acc)[U], const float (&v)[U]) {
+    static_assert(U == 2 || U == 4, "rows per step");
+    if constexpr (VL == 64) {
+#pragma unroll
+      for (int r = 0; r < U; ++r) acc[r] += v[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < U / 2; ++r) {
+        const u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[r]), __float_as_uint(v[r + U / 2]), false, false);
+        acc[r] += __uint_as_float(t[0]);
+        acc[r] += __uint_as_float(t[1]);
+      }
+    }
+  }
+  template <int U>
+  __device__ __forceinline__ static void tree_rows(const float (&acc)[U], float (&out)[U]) {
+    static_assert(U == 2 || U == 4, "rows per step");
+    float h[U / 2];  // rows r (lower half) and r + U/2 (upper half) after level 32
+#pragma unroll
+    for (int r = 0; r < U / 2; ++r) {
+      if constexpr (VL == 64) {
+        const u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r]), __float_as_uint(acc[r + U / 2]), false, false);
+        h[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+      } else {
+        h[r] = acc[r];
+      }
+    }
+    float v;
+    if constexpr (U == 4) {
+      const u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[0]), __float_as_uint(h[1]), false, false);
+      v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    } else {
+      const u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[0]), __float_as_uint(h[0]), false, false);
+      v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));  // row_shl:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));  // row_shl:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));  // row_shl:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));  // row_shl:1
+#pragma unroll
+    for (int r = 0; r < U; ++r)
+      out[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), U == 4 ? 16 * r : 32 * r));
+  }
   // stream / virtual lane of physical lane `tid`, and whether this lane keeps the virtual lane's draw number j
   // (VL = 64: the thread's own index within its node's group, which may span several waves)
   __device__ __forceinline__ static int vlane(int tid) { return VL == 64 ? tid : (tid & (VL - 1)); }

@@ -33,8 +33,20 @@ __device__ unsigned long long g_phi_trace[256];
 extern "C" int ammsb_debug_trace(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phi_trace), sizeof(unsigned long long) * (n < 256 ? n : 256)) == hipSuccess ? 0 : -2;
 }
+// per-block occupancy record: [block][0..3] = shader clock at start / end, 100 MHz wall clock at start / end,
+// [4] = HW_ID | XCC_ID << 32 (which CU / SIMD / wave slot the block ran on)
+__device__ unsigned long long g_phi_blk[16384 * 5];
+#define PHI_BLK(end) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { \
+    g_phi_blk[blockIdx.x * 5 + (end)] = __builtin_readcyclecounter(); \
+    g_phi_blk[blockIdx.x * 5 + 2 + (end)] = __builtin_amdgcn_s_memrealtime(); \
+    if (!(end)) g_phi_blk[blockIdx.x * 5 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
+                                               ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } while (0)
+extern "C" int ammsb_debug_blocks(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phi_blk), sizeof(unsigned long long) * 5 * (n_blocks < 16384 ? n_blocks : 16384)) == hipSuccess ? 0 : -2;
+}
 #else
 #define PHI_TRACE(slot) do { } while (0)
+#define PHI_BLK(end) do { } while (0)
 #endif
 
 namespace {
@@ -52,6 +64,7 @@ struct PhiArgs {
   uint32_t K, n;
   float eps_t, alpha, epsilon, Nn;
   uint32_t noise_on;
+  uint32_t rows_nt;  // neighbour rows requested with the non-temporal hint (a pi that does not fit the last-level cache)
   const ammsb_step_desc* desc;  // non-null (captured graph): n_nodes and eps_t come from here, all groups run
   unsigned long long* stamps;   // optional (with desc): block 0 notes the device time at which it starts
 };
@@ -470,9 +483,15 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
     const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
     const float* src = rpm_row(a.pi, nbr) + (W == 1 ? 4 * tid : L * (ln >> 4) + 64 * wv + 4 * (ln & 15));
     char* dst = wave_smem + slot * (KW * sizeof(float));
+    if (a.rows_nt) {
 #pragma unroll
-    for (int t = 0; t < PIECES; ++t)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+      for (int t = 0; t < PIECES; ++t)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+    } else {
+#pragma unroll
+      for (int t = 0; t < PIECES; ++t)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 0);
+    }
   };
 
   // WG_SUM over L lanes (sum.cc:20-29): levels L/2 .. 64 fold wave i + s onto wave i, then the in-wave tree
@@ -679,8 +698,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
 
   const PhiStep st = phi_step(a);
   note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
-  const uint32_t g = a.group_begin + blockIdx.x;
-  if (g >= st.group_end) return;  // block-uniform
+  const uint32_t g0 = a.group_begin + blockIdx.x;
+  if (g0 >= st.group_end) return;  // block-uniform
+  PHI_BLK(0);
   const uint32_t n = a.n;
   const float EPS = a.epsilon;
   if (a.noise_on) zig_load(&zig);
@@ -695,18 +715,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
     beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
   }
   ammsb_seed rs = {0, 0};
-  if (a.noise_on) rs = a.seeds[(uint64_t)g * VL + VLn::vlane(tid)];
 
   auto request = [&](uint32_t q, uint32_t slot) {
     const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[q] & 0x7fffffffu);
     const float* src = rpm_row(a.pi, nbr) + 4 * tid;
     char* dst = smem + slot * (KW * sizeof(float));
+    if (a.rows_nt) {
 #pragma unroll
-    for (int t = 0; t < PIECES; ++t)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+      for (int t = 0; t < PIECES; ++t)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+    } else {
+#pragma unroll
+      for (int t = 0; t < PIECES; ++t)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 0);
+    }
   };
 
   PHI_TRACE(0);
+  // (gridDim.x < groups only with AMMSB_PHI_PERSIST, see launch_phi_lds2: block b then takes groups b, b + gridDim.x, ...;
+  // virtual group g keeps stream g L + l and its nodes whichever block runs it)
+  for (uint32_t g = g0; g < st.group_end; g += gridDim.x) {
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * VL + VLn::vlane(tid)];
   for (uint64_t i = g; i < st.n_nodes; i += st.G) {
     const uint32_t node = a.nodes[i];
     __syncthreads();  // orders the LDS traffic of consecutive nodes
@@ -822,6 +851,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       // pass 1 of all U rows (phi.cc:241-253): probs[] in place of the row, lane partials in ascending column order
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
+        float vx[U], vy[U];
 #pragma unroll
         for (int r = 0; r < U; ++r) {
           const f32x2 pin = f32x2{row[r][ln + 128 * p], row[r][ln + 128 * p + 64]};
@@ -833,14 +863,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
             row[r][ln + 128 * p] = pr.x;
             row[r][ln + 128 * p + 64] = pr.y;
           }
-          VLn::chain(part[r], pr.x);
-          VLn::chain(part[r], pr.y);
+          vx[r] = pr.x;
+          vy[r] = pr.y;
           lo[r] = fminf(fminf(lo[r], fabsf(pr.x)), fabsf(pr.y));
         }
+        VLn::template chain_rows<U>(part, vx);  // all U rows' chains advance by the column pair (ammsb_dev.h)
+        VLn::template chain_rows<U>(part, vy);
       }
+      VLn::template tree_rows<U>(part, psum);  // phi.cc:254-257
 #pragma unroll
       for (int r = 0; r < U; ++r) {
-        psum[r] = VLn::tree(part[r]);  // phi.cc:254-257
         fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
         all_fast = all_fast && fast[r];
       }
@@ -937,12 +969,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void up
       const f32x2 aa = phi_k + drift;
       const f32x2 s2 = aa + bb;
       const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
-      __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + tid + 2 * L * p);
-      __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
+      if (a.rows_nt) {  // (a small pi: the row stays in the cache for update_pi, the next kernel)
+        __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + tid + 2 * L * p);
+        __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
+      } else {
+        out[tid + 2 * L * p] = v0 > 1e-24f ? v0 : 1e-24f;
+        out[tid + 2 * L * p + L] = v1 > 1e-24f ? v1 : 1e-24f;
+      }
     }
     PHI_TRACE(5);
   }
   if (a.noise_on && tid < VL) a.seeds[(uint64_t)g * VL + tid] = rs;
+  }
+  PHI_BLK(1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1383,8 +1422,416 @@ int launch_phi_wide(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
   }();
   (void)big;
   static const std::string name = ammsb_kname("update_phi_wide_kernel<%d, %d, %d>", KPT, RW, VL);
-  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
+  ctx->kernel_name[AMMSB_KN_PHI_SMALL] = name.c_str();  // (its own slot: a loop enqueues both forms for every step)
   update_phi_wide_kernel<KPT, RW, VL><<<n_groups, 64 * (RW + 1), lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K = 256, large launches, OPT-IN (AMMSB_PHI_STREAM=1): persistent one-wave blocks that stream the neighbour rows of
+// consecutive nodes as one sequence and fetch the next node's prologue while the current node's rows are being reduced.
+//
+// Why it was built: in-kernel stamps of update_phi_lds2_kernel<4, 8, 4> under load
+// (profiles/r03_phi_k256_trace_loaded.txt) show a node taking ~42 000 cycles of which 9 400 are prologue -- node id ->
+// neighbour ids -> edge-set probes / own row / phi_sum, three dependent round trips, plus the ziggurat tables and the
+// beta row loaded once per NODE because a block is a node -- with nothing in flight for the wave meanwhile.  Here a
+// block walks several virtual groups (g = b, b + B, ...; B = what the chip holds), the tables and beta are loaded once
+// per block, and during node k's row loop the wave issues node k+1's prologue in stages (ids; probe bins; probe test
+// and link flags into the other half of a double-buffered id list; own row, phi_sum, stream state) and requests node
+// k+1's first rows in node k's last step: the row stream never drains.  Virtual group g still owns stream g L + l and
+// node(s) g (, g + G): arithmetic, WG_SUM order and draws are update_phi_lds2_kernel's, bit for bit (tests).
+// The counted vmcnt waits stay valid with the extra requests around: every prologue request is issued AFTER a step's
+// wait and before the next step's row requests, i.e. it is OLDER than everything a later wait leaves outstanding.
+//
+// What was measured (profiles/r03_c2_stream_ab.log, r03_phi_k256_stream_trace.txt): the stamps confirm the design --
+// no step waits for rows any more and the staged prologue costs 300 - 700 cycles of issue per stage -- but the kernel
+// is SLOWER than the one it was to replace, 82 against 69 us at C2 (wg 32: 91 against 70).  Its staging area and the
+// registers that carry a second node's state leave 10 - 11 blocks per CU where update_phi_lds2_kernel has 16, and at
+// K = 256 the launch is not waiting for memory in the first place: the SQ counters put the VALU at 74 % busy while all
+// 16 waves of a CU are resident (2 611 VALU instructions per node, profiles/r03_c2_pmc_sq.txt), so what the prologue
+// overlap buys is paid back by the lost waves.  Kept opt-in and tested; not dispatched by default.
+template <int KPT, int D, int U, int VL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void update_phi_stream_kernel(const PhiArgs a) {
+  constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
+  using VLn = VLane<VL>;
+  constexpr int KV = KPT * VLn::PER;  // normals per virtual lane
+  static_assert(KPT == U && D == 2 * U && PIECES == 1, "K = 256: four rows per step, two steps in the ring");
+  // LDS: [D][KW] ring | [2][64] u32 id lists (id | link bit) | staging of the NEXT node's prologue, all of it filled by
+  // LDS-DMA: [64] neighbour ids, [2][64] node id (64 copies), then 4 KiB that hold the four 16-byte halves of the probes'
+  // two bins ([4][64][16 B]) and later, once those have been tested, the node's own row (1 KiB), its group's stream
+  // states (1 KiB) and phi_sum (64 copies).
+  // Why LDS-DMA for a few dozen bytes: a plain load inside this loop makes hipcc's wait-count pass emit vmcnt(0) at
+  // the load's first use (it cannot count across the loop's branches), which drains the row requests in flight -- the
+  // first form of this kernel had seven such drains per node and was slower than the kernel it replaces.  DMA writes
+  // have no register result; their arrival is covered by the loop's own counted waits (they are always older than the
+  // requests a wait leaves outstanding) and they are read back with ordinary LDS loads.
+  extern __shared__ __align__(16) char smem[];
+  __shared__ ZigTables zig;
+  const int tid = threadIdx.x;
+  float* ring = reinterpret_cast<float*>(smem);
+  uint32_t* s_nb_all = reinterpret_cast<uint32_t*>(smem + (size_t)D * KW * sizeof(float));
+  uint32_t* st_ids = s_nb_all + 128;
+  uint32_t* st_node = st_ids + 64;
+  char* st_big = reinterpret_cast<char*>(st_node + 128);  // 4 KiB, 16-byte aligned (st_node is [2][64]: current, next)
+  float* st_row = reinterpret_cast<float*>(st_big);                          // [KW] the next node's own pi row
+  ammsb_seed* st_seeds = reinterpret_cast<ammsb_seed*>(st_big + 1024);       // [64] its group's stream states
+  float* st_phisum = reinterpret_cast<float*>(st_big + 2048);                // [64] copies of its phi_sum
+  auto dma4 = [&](const void* src_lane, void* dst_uniform) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src_lane, (lds_void_t*)dst_uniform, 4, 0, 0);
+  };
+  auto dma16 = [&](const void* src_lane, void* dst_uniform) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src_lane, (lds_void_t*)dst_uniform, 16, 0, 0);
+  };
+
+  const PhiStep st = phi_step(a);
+  if (st.n_nodes == 0) return;  // (uniform) a skipped step
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
+  const uint32_t B = gridDim.x, n = a.n, NIT = n / U;
+  PHI_TRACE(0);
+  const uint32_t g0 = a.group_begin + blockIdx.x;
+  if (g0 >= st.group_end) return;  // block-uniform
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  f32x2 bf[HP];
+  bool beta_safe = true;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    const float b0 = a.beta[2 * (tid + 2 * L * p) + 1];
+    const float b1 = a.beta[2 * (tid + 2 * L * p + L) + 1];
+    bf[p] = f32x2{b0 - EPS, b1 - EPS};
+    beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
+  }
+
+  // rows q0 .. q0+U-1 of the id list `nb` into the ring half `half`
+  auto request = [&](const uint32_t* nb, uint32_t q0, uint32_t half) {
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+      const uint32_t nbr = __builtin_amdgcn_readfirstlane(nb[q0 + r] & 0x7fffffffu);
+      const float* src = rpm_row(a.pi, nbr) + 4 * tid;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(smem + (size_t)(half * U + r) * (KW * sizeof(float))), 16, 0, 2);
+    }
+  };
+  auto wave_sync = [&]() {  // one wave: its LDS operations complete in order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- the first node of this block: plain prologue, parked in the staging area like every later node's
+  uint32_t cur_g = g0;
+  uint64_t cur_i = g0;
+  uint32_t sb = 0, gg = 0;  // id-list buffer of the current node; running count of row groups (ring half = gg & 1)
+  {
+    const uint32_t node0 = a.nodes[cur_i];
+    __syncthreads();  // the ziggurat tables
+    uint32_t nb = 0;
+    if ((uint32_t)tid < n) {
+      nb = a.neighbors[cur_i * n + tid];
+      if (set_has(a.set, make_edge(node0, nb))) nb |= 0x80000000u;
+    }
+    s_nb_all[tid] = nb;
+    st_node[tid] = node0;
+    st_phisum[tid] = a.phi_sum[node0];
+    const float* row_a = rpm_row(a.pi, node0);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) st_row[tid + 64 * j] = __builtin_nontemporal_load(row_a + tid + 64 * j);
+    ammsb_seed rs0 = {0, 0};
+    if (a.noise_on) rs0 = a.seeds[(uint64_t)cur_g * VL + VLn::vlane(tid)];
+    st_seeds[tid] = rs0;
+  }
+  wave_sync();
+  request(s_nb_all, 0, 0);
+  PHI_TRACE(1);
+  uint32_t trace_node = 0;
+
+  // A node's results are stored one step late -- behind the first wait of the NEXT node's row loop -- so that no
+  // counted wait ever has stores of unknown age in front of it (vmcnt counts stores and retires in order: stores
+  // issued between two row requests would have to be waited for before the later rows count as landed).
+  bool pend = false, pend_seeds = false;
+  float pend_v[KPT];
+  uint64_t pend_i = 0;
+  uint32_t pend_g = 0;
+  ammsb_seed pend_rs = {0, 0};
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) pend_v[j] = 0.0f;
+  auto flush = [&]() {
+    if (!pend) return;
+    float* out = a.phi_vec + pend_i * K;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      __builtin_nontemporal_store(pend_v[2 * p], out + tid + 2 * L * p);
+      __builtin_nontemporal_store(pend_v[2 * p + 1], out + tid + 2 * L * p + L);
+    }
+    if (pend_seeds && tid < VL) a.seeds[(uint64_t)pend_g * VL + tid] = pend_rs;
+    pend = false;
+  };
+
+  ammsb_seed rs = {0, 0};
+  bool take_seeds = true;  // the staged stream states belong to a group this block is entering
+  for (;;) {
+    // the item after this one: the group's second node (more nodes than groups), else the block's next group
+    uint32_t nx_g = cur_g;
+    uint64_t nx_i = cur_i + st.G;
+    if (nx_i >= st.n_nodes) {
+      nx_g = cur_g + B;
+      nx_i = nx_g;
+    }
+    const bool nx_valid = nx_g < st.group_end && nx_i < st.n_nodes;
+    const uint32_t* s_nb = s_nb_all + sb * 64;
+    float phi_sum = 1.0f, inv_phi_sum = 1.0f;
+    f32x2 pi_a[HP], grads[HP], rden[HP];
+    float nz[KPT];
+    bool node_safe = false;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      pi_a[p] = grads[p] = rden[p] = f32x2{0.0f, 0.0f};
+      nz[2 * p] = nz[2 * p + 1] = 0.0f;
+    }
+    const uint32_t sB = NIT / 2 - 1, sC = NIT - 2;  // (NIT >= 4: dispatch)
+    uint64_t nx_key = 0;
+    uint32_t nx_nb = 0;
+
+    for (uint32_t it = 0; it < NIT; ++it, ++gg) {
+      const uint32_t q = it * U;
+      float* row[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) row[r] = ring + ((gg & 1u) * U + r) * KW;
+      // every LDS read of the previous row group has been consumed; its half of the ring takes the next group:
+      // the current node's next rows, or -- in its last step -- the first rows of the next node
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (trace_node < 3) PHI_TRACE(8 + 32 * trace_node + 3 * it);
+      bool more = true;
+      if (it + 1 < NIT) request(s_nb, q + U, (gg + 1) & 1u);
+      else if (nx_valid) request(s_nb_all + (sb ^ 1u) * 64, 0, (gg + 1) & 1u);
+      else more = false;
+      // one of the node's normals per step, drawn while the rows are on their way (stream order = ascending column);
+      // the first step's draw waits until the stream state has been read from the staging area (below)
+      float z_now = 0.0f;
+      if (a.noise_on && it >= 1 && it < (uint32_t)KV) z_now = rng_normal(rs, &zig);
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U * PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (trace_node < 3) PHI_TRACE(8 + 32 * trace_node + 3 * it + 1);
+
+      if (it == 0) {
+        flush();  // the previous node's row (and stream state)
+        // this node's own data, staged by the previous node's last step (or by the block's prologue)
+        phi_sum = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st_phisum[0])));
+        inv_phi_sum = 1.0f / phi_sum;
+        node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          pi_a[p] = f32x2{st_row[tid + 2 * L * p], st_row[tid + 2 * L * p + L]};
+          const f32x2 den = pi_a[p] * phi_sum;
+          rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
+          node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
+          const f32x2 ep = den * st.eps_t;
+          nz[2 * p] = sqrtf(ep.x);
+          nz[2 * p + 1] = sqrtf(ep.y);
+        }
+        if (take_seeds) rs = st_seeds[tid];
+        if (a.noise_on && 0 < KV) z_now = rng_normal(rs, &zig);
+      }
+      if (a.noise_on && it < (uint32_t)KV && VLn::keeps(tid, it)) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+          if ((uint32_t)j == it / VLn::PER) nz[j] = nz[j] * z_now;
+      }
+
+      // ---- the next node's prologue, a stage at a time, all through LDS-DMA (see the top of the kernel)
+      if (nx_valid) {
+        if (it == 0) {  // its neighbour ids and its node id
+          dma4(a.neighbors + nx_i * n + ((uint32_t)tid < n ? (uint32_t)tid : n - 1), st_ids);
+          dma4(a.nodes + nx_i, st_node + 64);  // (the other half of [2][64]: the current node's id stays readable)
+        }
+        if (it == sB) {  // the four 16-byte halves of the two bins each lane's probe looks at
+          const uint32_t nx_node = __builtin_amdgcn_readfirstlane(st_node[64]);
+          nx_nb = st_ids[tid];
+          nx_key = make_edge(nx_node, nx_nb);
+          const uint64_t h1 = fast_mod(kSetPrimes[2 * a.set.prime_idx] * nx_key, a.set.mod);
+          const uint64_t h2 = fast_mod(nx_key ^ kSetPrimes[2 * a.set.prime_idx + 1], a.set.mod);
+          const uint64_t* b1 = a.set.slots + h1 * 4;
+          const uint64_t* b2 = a.set.slots + (a.set.num_bins + h2) * 4;
+          dma16(b1, st_big);
+          dma16(b1 + 2, st_big + 1024);
+          dma16(b2, st_big + 2048);
+          dma16(b2 + 2, st_big + 3072);
+        }
+        if (it == sC) {  // test them; the id list of the next node is complete
+          // (read with explicit instructions: hipcc puts a vmcnt(0) in front of an LDS load it can see aliasing an
+          // LDS-DMA target, which here would drain the row requests; the counted wait above already covers the probes)
+          ulonglong2 pv[4];
+          const uint32_t lds_at = (uint32_t)(uintptr_t)(lds_void_t*)(st_big + 16 * tid);
+          asm volatile(
+              "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+              "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+              : "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3])
+              : "v"(lds_at)
+              : "memory");
+          bool hit = false;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) hit = hit || pv[w].x == nx_key || pv[w].y == nx_key;
+          uint32_t v = 0;
+          if ((uint32_t)tid < n) v = nx_nb | (hit ? 0x80000000u : 0u);
+          s_nb_all[(sb ^ 1u) * 64 + tid] = v;  // read by the request of the last step (LDS operations of a wave are ordered)
+        }
+        if (it == NIT - 1) {  // its own row, phi_sum and stream states take the probe area (tested two steps ago)
+          const uint32_t nx_node = __builtin_amdgcn_readfirstlane(st_node[64]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of the area has returned
+          dma16(rpm_row(a.pi, nx_node) + 4 * tid, st_row);
+          dma4(a.phi_sum + nx_node, st_phisum);
+          if (a.noise_on && nx_g != cur_g) dma16(a.seeds + (uint64_t)nx_g * VL + VLn::vlane(tid), st_seeds);
+        }
+      }
+
+      float ee[U], sg[U], part[U], lo[U], psum[U];
+      f32x2 prr[U][HP];
+      bool fast[U], all_fast = true;
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        const bool y = (__builtin_amdgcn_readfirstlane(s_nb[q + r]) >> 31) != 0;
+        ee[r] = y ? EPS : 1.0f - EPS;
+        sg[r] = y ? 1.0f : -1.0f;  // e - pin (beta - EPS) == e + (-(pin (beta - EPS))): the negation is exact
+        part[r] = 0.0f;
+        lo[r] = 1.0f;
+      }
+      // pass 1 of all U rows (phi.cc:241-253): probs[], lane partials in ascending column order
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        float vx[U], vy[U];
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const f32x2 pin = f32x2{row[r][tid + 128 * p], row[r][tid + 128 * p + 64]};
+          const f32x2 tt = (pin * bf[p]) * sg[r] + ee[r];
+          const f32x2 pr = pi_a[p] * tt;
+          prr[r][p] = pr;
+          vx[r] = pr.x;
+          vy[r] = pr.y;
+          lo[r] = fminf(fminf(lo[r], fabsf(pr.x)), fabsf(pr.y));
+        }
+        VLn::template chain_rows<U>(part, vx);  // all U rows' chains advance by the column pair (ammsb_dev.h)
+        VLn::template chain_rows<U>(part, vy);
+      }
+      VLn::template tree_rows<U>(part, psum);  // phi.cc:254-257
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
+        all_fast = all_fast && fast[r];
+      }
+      // pass 2 (phi.cc:259-263): grads += (probs / probs_sum) / (pi * phi_sum) - 1 / phi_sum, rows in order
+      if (all_fast) {
+        float ps = phi_sum;
+        asm volatile("" : "+v"(ps));  // keeps pi_a * phi_sum from being hoisted into KPT more registers
+        f32x2 s2[U], r2[U];
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const float rc = exact_rcp(psum[r]);
+          s2[r] = f32x2{psum[r], psum[r]};
+          r2[r] = f32x2{rc, rc};
+        }
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 den = pi_a[p] * ps;
+          f32x2 v[U];
+#pragma unroll
+          for (int r = 0; r < U; ++r) v[r] = div_exact3(div_exact3(prr[r][p], s2[r], r2[r]), den, rden[p]);
+#pragma unroll
+          for (int r = 0; r < U; ++r) grads[p] += v[r] - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const float probs_sum = psum[r];
+          if (fast[r]) {
+            const float rps = exact_rcp(probs_sum);
+            const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+              f32x2 qv = div_exact3(prr[r][p], psum2, rps2);
+              qv = div_exact3(qv, pi_a[p] * phi_sum, rden[p]);
+              grads[p] += qv - inv_phi_sum;
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+              const f32x2 den = pi_a[p] * phi_sum;
+              float v0 = prr[r][p].x / probs_sum, v1 = prr[r][p].y / probs_sum;
+              v0 = v0 / den.x;
+              v1 = v1 / den.y;
+              grads[p] += f32x2{v0 - inv_phi_sum, v1 - inv_phi_sum};
+            }
+          }
+        }
+      }
+    }
+    if (trace_node < 3) PHI_TRACE(8 + 32 * trace_node + 3 * NIT);
+    ++trace_node;
+    // normals the loop did not get to (fewer steps than normals per virtual lane)
+    if (a.noise_on) {
+#pragma unroll 1
+      for (uint32_t j = NIT; j < (uint32_t)KV; ++j) {
+        const float z = rng_normal(rs, &zig);
+        if (VLn::keeps(tid, j)) {
+#pragma unroll
+          for (int c = 0; c < KPT; ++c)
+            if ((uint32_t)c == j / VLn::PER) nz[c] = nz[c] * z;
+        }
+      }
+    }
+
+    // SGLD step, phi.cc:265-274 (parked: stored behind the next node's first wait, or below if this was the last)
+    const float half = st.eps_t / 2;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      const f32x2 bb = f32x2{nz[2 * p], nz[2 * p + 1]};
+      const f32x2 phi_k = pi_a[p] * phi_sum;
+      const f32x2 ng = grads[p] * a.Nn;
+      f32x2 in = a.alpha - phi_k;
+      in = in + ng;
+      const f32x2 drift = in * half;
+      const f32x2 aa = phi_k + drift;
+      const f32x2 s2 = aa + bb;
+      const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
+      pend_v[2 * p] = v0 > 1e-24f ? v0 : 1e-24f;
+      pend_v[2 * p + 1] = v1 > 1e-24f ? v1 : 1e-24f;
+    }
+    pend = true;
+    pend_i = cur_i;
+    // the group's stream goes back when the block leaves the group
+    pend_seeds = a.noise_on && (!nx_valid || nx_g != cur_g);
+    if (pend_seeds) {
+      pend_g = cur_g;
+      pend_rs = rs;
+    }
+    take_seeds = nx_g != cur_g;
+    if (!nx_valid) {
+      flush();
+      break;
+    }
+    cur_g = nx_g;
+    cur_i = nx_i;
+    sb ^= 1u;
+  }
+}
+
+template <int KPT, int D, int U, int VL>
+int launch_phi_stream(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = (size_t)D * sizeof(float) * 64 * KPT + 5 * 64 * sizeof(uint32_t) + 4096;  // ring, id lists, staging
+  static const int per_cu = [] {  // resident one-wave blocks per CU (registers, LDS): the persistent grid is that times the CUs
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, update_phi_stream_kernel<KPT, D, U, VL>, 64,
+                                                     (size_t)D * sizeof(float) * 64 * KPT + 5 * 64 * sizeof(uint32_t) + 4096) != hipSuccess || v < 1)
+      v = 8;
+    return v;
+  }();
+  // as many blocks as the chip holds -- fewer if that makes every block walk the same number of groups (8193 groups on
+  // 3072 slots: 2731 blocks of three, not 3072 of which a third idles through the last round)
+  const uint32_t max_blocks = (uint32_t)per_cu * (uint32_t)ctx->num_cus;
+  const uint32_t rounds = (n_groups + max_blocks - 1) / max_blocks;
+  uint32_t blocks = (n_groups + rounds - 1) / rounds;
+  static const std::string name = ammsb_kname("update_phi_stream_kernel<%d, %d, %d, %d>", KPT, D, U, VL);
+  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
+  update_phi_stream_kernel<KPT, D, U, VL><<<blocks, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1394,7 +1841,29 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
   const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
   static const std::string name = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d, %d>", KPT, D, U, VL);
   ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
-  update_phi_lds2_kernel<KPT, D, U, VL><<<n_groups, 64, lds, s>>>(a);
+  // AMMSB_PHI_PERSIST=1|2|3 (A/B runs): a persistent grid for launches of more groups than the chip holds at once
+  // (1: resident slots when the excess over whole rounds is small, else the groups spread evenly over the fewest rounds;
+  // 2: always the resident slots; 3: always the even spread).  Measured equal or slightly slower than one block per
+  // group at C2 (69.6 - 71.3 against 68.5 - 70.2 us): not the default.
+  static const int mode = [] {
+    const char* f = getenv("AMMSB_PHI_PERSIST");
+    return f ? atoi(f) : 0;
+  }();
+  static const int per_cu = [] {
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, update_phi_lds2_kernel<KPT, D, U, VL>, 64,
+                                                     (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + 128) != hipSuccess || v < 1)
+      v = 0;
+    return v;
+  }();
+  uint32_t grid = n_groups;
+  const uint64_t slots = (uint64_t)per_cu * (uint64_t)ctx->num_cus;
+  if (mode > 0 && slots > 0 && n_groups > slots) {
+    const uint64_t rounds = (n_groups + slots - 1) / slots;
+    grid = (uint32_t)((n_groups + rounds - 1) / rounds);
+    if (mode == 2 || (mode == 1 && n_groups - (rounds - 1) * slots <= slots / 16)) grid = (uint32_t)slots;
+  }
+  update_phi_lds2_kernel<KPT, D, U, VL><<<grid, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1831,6 +2300,17 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   a.epsilon = p.epsilon;
   a.Nn = (1.0f * (float)p.N) / (float)p.num_node_sample;  // phi.cc:265
   a.noise_on = (flags & AMMSB_NOISE_OFF) ? 0u : 1u;
+  {
+    static const int nt_mode = [] {  // AMMSB_PHI_NT=0|1 forces the hint off / on (A/B runs)
+      const char* f = getenv("AMMSB_PHI_NT");
+      return f ? atoi(f) : -1;
+    }();
+    // Non-temporal row requests pay when pi is far larger than the last-level cache (C3, 4 GB: -4 % per launch,
+    // same-box A/B in round 1) and cost when it fits (C2, 100 MB in the 256 MB Infinity Cache, every row read 2.7
+    // times per launch: 72.4 -> 66.3 us without the hint, profiles/r03_nt_ab.log).
+    const uint64_t pi_bytes = pi->num_rows * pi->num_cols * sizeof(float);
+    a.rows_nt = nt_mode >= 0 ? (uint32_t)nt_mode : (pi_bytes > (256ull << 20) ? 1u : 0u);
+  }
   if (a.group_begin >= a.group_end) return AMMSB_OK;
   const uint32_t n_groups = a.group_end - a.group_begin;
   hipStream_t s = as_stream(stream);
@@ -1860,6 +2340,16 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
     if (p.K == 256) return rw_alt == 8 ? launch_phi_wide<4, 8, 32>(ctx, a, n_groups, s) : launch_phi_wide<4, 15, 32>(ctx, a, n_groups, s);
     if (p.K == 512) return rw_alt == 8 ? launch_phi_wide<8, 8, 32>(ctx, a, n_groups, s) : launch_phi_wide<8, 11, 32>(ctx, a, n_groups, s);
     return rw_alt == 8 ? launch_phi_wide<16, 8, 32>(ctx, a, n_groups, s) : launch_phi_wide<16, 11, 32>(ctx, a, n_groups, s);
+  }
+  // K = 256, large launches: persistent blocks streaming across nodes (update_phi_stream_kernel), opt-in with
+  // AMMSB_PHI_STREAM=1: bit-identical but slower than the one-block-per-node kernels (see the kernel's comment).
+  static const bool stream_form = [] {
+    const char* f = getenv("AMMSB_PHI_STREAM");
+    return f && atoi(f) != 0;
+  }();
+  if (stream_form && !force_reg && !force_gen && (wg == 32 || wg == 64) && p.K == 256 && pi->num_cols % 4 == 0 &&
+      a.n >= 16 && a.n <= 64 && a.n % 4 == 0 && n_groups > 1024) {
+    return wg == 64 ? launch_phi_stream<4, 8, 4, 64>(ctx, a, n_groups, s) : launch_phi_stream<4, 8, 4, 32>(ctx, a, n_groups, s);
   }
   // Short rows, two nodes per wave (update_phi_pair_kernel): K = 256 / 512 at wg 32 or 64, n a multiple of 2.
   // Opt-in (AMMSB_PHI_PAIR=1; 2 / 3 pick other ring depths / rows per step): bit-identical, but SLOWER at C2 in same-box
@@ -1917,6 +2407,8 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
           if (ring == 4) return launch_phi_lds<4, 1, 4>(ctx, a, n_groups, s);
           if (ring == 8 || (a.n & 1)) return launch_phi_lds<4, 1, 8>(ctx, a, n_groups, s);
           if (ring == 42) return launch_phi_lds2<4, 4, 2>(ctx, a, n_groups, s);  // A/B: two rows, four slots
+          // (tried: <4, 16, 4>, twelve rows in flight per wave and nine waves per CU instead of sixteen: 88 us against 69
+          // at C2.  Fewer waves cost more than deeper prefetch gains, as at K = 1024 below.)
           if (ring == 22 || (a.n & 3)) return launch_phi_lds2<4, 8, 2>(ctx, a, n_groups, s);  // two rows per iteration
           return launch_phi_lds2<4, 8, 4>(ctx, a, n_groups, s);                               // four (n % 4 == 0)
         case 8:
@@ -1929,6 +2421,8 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
             return f ? atoi(f) : 1;
           }();
           if (nb == 2) return launch_phi_lds<16, 1, 2, 2>(ctx, a, n_groups, s);
+          // A/B: three rows in flight, 8 waves per CU -- C3 update_phi 1.76 -> 2.04 ms (profiles/r03_c3_ring_ab.log)
+          if (ring == 4) return launch_phi_lds<16, 1, 4>(ctx, a, n_groups, s);
           return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
         }
         case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);

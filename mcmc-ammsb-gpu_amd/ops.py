@@ -111,12 +111,17 @@ class Context:
     def check(self, rc):
         check(rc, self._ctx)
 
-    KERNELS = ("update_phi", "update_pi", "beta_grads", "perplexity")
+    KERNELS = ("update_phi", "update_pi", "beta_grads", "perplexity", "update_phi_small")
 
     def kernel_names(self):
         """Names of the kernels the last update_phi / update_pi / gradient / perplexity calls on this context
-        dispatched to, spelled as in a rocprofv3 kernel trace (ammsb_last_kernel_name)."""
-        return {k: self.lib.ammsb_last_kernel_name(self.handle, i).decode() for i, k in enumerate(self.KERNELS)}
+        dispatched to, spelled as in a rocprofv3 kernel trace (ammsb_last_kernel_name).  "update_phi" is the form large
+        launches take, "update_phi_small" the several-waves-per-node form of launches of at most 512 groups (link
+        mini-batches); a context that has only ever made small launches reports that one under both keys."""
+        names = {k: self.lib.ammsb_last_kernel_name(self.handle, i).decode() for i, k in enumerate(self.KERNELS)}
+        if not names["update_phi"]:
+            names["update_phi"] = names["update_phi_small"]
+        return names
 
     def close(self):
         if self._ctx:

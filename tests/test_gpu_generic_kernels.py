@@ -153,8 +153,7 @@ from test_gpu_parity import Problem
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
-for N, K, n, n_nodes, L in [(2048, 256, 32, 201, 64), (2048, 256, 32, 200, 32), (2048, 256, 6, 100, 64),
-                            (2048, 512, 32, 101, 64), (2048, 512, 8, 100, 32), (70000, 256, 4, 65535 + 700, 64)]:
+for N, K, n, n_nodes, L in %(cases)s:
     for noise in (False, True):
         pr = Problem(orc, hip, N, K, n, n_nodes, deg=4 if N > 10000 else 16)
         upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, n_nodes, (42, 43), L,
@@ -164,7 +163,7 @@ for N, K, n, n_nodes, L in [(2048, 256, 32, 201, 64), (2048, 256, 32, 200, 32), 
         for step in (1, 2):
             upd(pr.nodes, pr.nb, n_nodes)
             pr.sync()
-            assert "pair_kernel" in pr.ctx.kernel_names()["update_phi"], pr.ctx.kernel_names()
+            assert %(kernel)r in pr.ctx.kernel_names()["update_phi"], pr.ctx.kernel_names()
             want = orc.update_phi(pr.p_orc, pr.beta_h, pi_h.reshape(-1), phi_sum_h, pr.oset, pr.nodes_h,
                                   pr.nb_h.reshape(-1), step, seeds, L, 1, noise)
             got = upd.phi_vec.cpu().numpy()[:n_nodes]
@@ -186,7 +185,26 @@ def test_two_nodes_per_wave_update_phi(orc):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device (no fallback path exists)")
     env = dict(os.environ, AMMSB_PHI_PAIR="1")
-    script = PAIR_CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    cases = [(2048, 256, 32, 201, 64), (2048, 256, 32, 200, 32), (2048, 256, 6, 100, 64),
+             (2048, 512, 32, 101, 64), (2048, 512, 8, 100, 32), (70000, 256, 4, 65535 + 700, 64)]
+    script = PAIR_CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "cases": repr(cases), "kernel": "pair_kernel"}
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "pair ok" in out.stdout
+
+
+def test_persistent_streaming_update_phi(orc):
+    """update_phi_stream_kernel (opt-in, AMMSB_PHI_STREAM=1; K = 256, launches of more than 1024 groups): persistent
+    one-wave blocks walk several virtual groups and fetch the next node's prologue through LDS-DMA while the current
+    node's rows are reduced.  Work-group sizes 32 and 64, n = 16 / 20 / 32, more nodes than groups (a group's second
+    node follows its first in the same block)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no fallback path exists)")
+    env = dict(os.environ, AMMSB_PHI_STREAM="1")
+    cases = [(20000, 256, 32, 5000, 64), (20000, 256, 16, 3001, 32), (20000, 256, 20, 2000, 64),
+             (70000, 256, 16, 65535 + 900, 64)]
+    script = PAIR_CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "cases": repr(cases), "kernel": "stream_kernel"}
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "pair ok" in out.stdout

@@ -304,6 +304,12 @@ PHI_CASES = [
     (2048, 512, 7, 100, 32),    # update_phi_lds_kernel<8, 1, 4, 1, 32>
     (512, 2048, 8, 40, 32),     # update_phi_lds_kernel<32, 1, 2, 1, 32>: 64 columns per work-item
     (512, 2048, 70, 20, 32),    # more neighbours than normals per virtual lane
+    # K = 256, more than 1024 nodes: the persistent streaming kernel (update_phi_stream_kernel) -- blocks walk several
+    # groups, the next node's prologue is fetched under the current node's rows
+    (20000, 256, 32, 5000, 64),
+    (20000, 256, 16, 3001, 32),    # odd node count, four steps per node (the three prologue stages back to back)
+    (20000, 256, 20, 2000, 64),    # more steps than stages, fewer than normals at wg 32
+    (70000, 256, 16, 65535 + 900, 64),   # more nodes than groups: a group's second node continues its stream
     (1024, 1024, 33, 30, 64),   # link-batch sized launches: n not a multiple of the 8 row waves
     (1024, 1024, 3, 30, 32),    # fewer neighbours than row waves
     (1024, 512, 13, 50, 64),
