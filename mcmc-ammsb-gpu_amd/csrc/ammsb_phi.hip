@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
 // results are bit-identical (same tests).  Needs an even n; odd n takes the single-row kernel.
 // VL = 32: the reference work-group size 32 in the same one-wave-per-node layout (see update_phi_lds_kernel).
 template <int KPT, int D, int U, int VL = 64>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void update_phi_lds2_kernel(const PhiArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT == 4 ? 4 : 3))) void update_phi_lds2_kernel(const PhiArgs a) {
   constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
   using VLn = VLane<VL>;
   constexpr int KV = KPT * VLn::PER;  // columns (= normals) per virtual lane
