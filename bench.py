@@ -401,7 +401,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
                 dl = lambda a, b: round(float((st[okl, b] - st[okl, a]).mean()) * 1e-6, 5)  # noqa: E731  (ms)
                 kernels["link_steps_ms"] = {"update_phi": dl(0, 1), "update_pi": dl(1, 2), "beta_grads": dl(2, 3),
                                             "sum_grads+update_theta": dl(3, 4), "wait_for_sampler": dl(4, 5),
-                                            "steps": int(okl.sum()), "update_phi_kernel": names.get("update_phi_small", "")}
+                                            "steps": int(okl.sum()), "update_phi_kernel": names.get("update_phi_small") or names["update_phi"]}
     else:
         launches = [(a.elapsed_time(b) * 1e-3, nn, g) for a, b, nn, g in ev]
     big = [(t, nn, g) for t, nn, g in launches if nn > m // 2]

@@ -762,7 +762,21 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
   const uint32_t h = threadIdx.x & 1, r = threadIdx.x >> 1;
   const uint32_t c = blockIdx.x * 8 + 4 * h;
   float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  for (uint32_t p = r; p < P; p += 128) {
+  // (the loads of four partial rows are issued together; the adds keep the row order p = r, r + 128, ...)
+  uint32_t p = r;
+  for (; p + 384 < P; p += 512) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(partials + (uint64_t)(p + 128 * i) * cols + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s.x += v[i].x;
+      s.y += v[i].y;
+      s.z += v[i].z;
+      s.w += v[i].w;
+    }
+  }
+  for (; p < P; p += 128) {
     const float4 v = *reinterpret_cast<const float4*>(partials + (uint64_t)p * cols + c);
     s.x += v.x;
     s.y += v.y;

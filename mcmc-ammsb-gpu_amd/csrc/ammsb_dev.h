@@ -342,6 +342,21 @@ struct Group {
     constexpr int W = L < 64 ? L : 64;
     if constexpr (W == 64 && sizeof(T) == 4 && __is_same(T, float)) {
       return wave_tree64(v);
+    } else if constexpr (W == 32 && sizeof(T) == 4 && __is_same(T, float)) {
+      // two groups of 32 per wave (the reference's default work-group size): wave_tree64 without its first level on
+      // both halves at once -- v_permlane16_swap folds lanes l + 16 onto l in each half, four DPP adds fold l + 8 ..
+      // l + 1, lanes 0 and 32 are handed to their halves through SGPRs.  (The XOR butterfly below needs five
+      // ds_bpermute round trips; the short-row kernels at K = 32 are nothing but this latency.)
+      typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+      const u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      float x = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+      x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x108, 0xf, 0xf, true));  // row_shl:8
+      x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x104, 0xf, 0xf, true));  // row_shl:4
+      x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x102, 0xf, 0xf, true));  // row_shl:2
+      x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x101, 0xf, 0xf, true));  // row_shl:1
+      const float lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 0));
+      const float hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 32));
+      return (threadIdx.x & 32) ? hi : lo;
     } else {
 #pragma unroll
       for (int p2 = W >> 1; p2 > 0; p2 >>= 1) v += __shfl_xor(v, p2, 64);

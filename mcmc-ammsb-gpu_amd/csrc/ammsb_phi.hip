@@ -296,6 +296,23 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
             }
           }
         };
+        if (KPT == 1 && n <= 32) {
+          // one column per lane, at most 32 neighbours (the reference's default, main.cc:58): ALL rows are requested before the first is
+          // consumed -- 32 KPT registers -- so a node costs one row round trip instead of one per group of four
+          // (C1: a row group's arithmetic is shorter than the latency of the next group's rows, the loop was a chain
+          // of eight round trips).  Row indices are clamped, not predicated (see FULL above).
+          float all[8][4][KPT];
+#pragma unroll
+          for (int gq = 0; gq < 8; ++gq)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const uint32_t q = (uint32_t)(4 * gq + d);
+              load_row(all[gq][d], q < n ? q : n - 1);
+            }
+#pragma unroll
+          for (int gq = 0; gq < 8; ++gq)
+            if ((uint32_t)(4 * gq) < n) consume4(all[gq], 4 * gq);
+        } else {
 #pragma unroll
         for (int d = 0; d < 4; ++d) load_row(buf[d], d);
         for (uint32_t q0 = 0; q0 < n; q0 += 4) {
@@ -310,6 +327,7 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiAr
 #pragma unroll
               for (int j = 0; j < KPT; ++j) buf[d][j] = nxt[d][j];
           }
+        }
         }
       }
     }
