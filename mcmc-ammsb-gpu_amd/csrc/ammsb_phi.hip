@@ -2401,6 +2401,9 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
       case 512:
         if (a.n & 1) return launch_phi_lds<8, 1, 4, 1, 32>(ctx, a, n_groups, s);
         return launch_phi_lds2<8, 4, 2, 32>(ctx, a, n_groups, s);
+      // (tried: two rows per step at K = 1024 -- update_phi_lds2_kernel<16, 4, 2, VL>, which at wg 32 also halves the
+      // swaps of the chain -- 2.19 against 1.88 ms at wg 32, 2.05 against 1.73 ms at wg 64 on C3: its 20 KiB of LDS
+      // leave 8 waves per CU where the one-row kernel has 11.)
       case 1024: return launch_phi_lds<16, 1, 2, 1, 32>(ctx, a, n_groups, s);
       case 2048: return launch_phi_lds<32, 1, 2, 1, 32>(ctx, a, n_groups, s);
     }
