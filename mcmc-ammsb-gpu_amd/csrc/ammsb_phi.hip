@@ -1881,7 +1881,11 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
     grid = (uint32_t)((n_groups + rounds - 1) / rounds);
     if (mode == 2 || (mode == 1 && n_groups - (rounds - 1) * slots <= slots / 16)) grid = (uint32_t)slots;
   }
-  update_phi_lds2_kernel<KPT, D, U, VL><<<grid, 64, lds, s>>>(a);
+  static const size_t pad = [] {  // AMMSB_PHI_LDS_PAD=<bytes>: extra LDS per block, i.e. fewer resident blocks per CU (experiments)
+    const char* f = getenv("AMMSB_PHI_LDS_PAD");
+    return f ? (size_t)atoi(f) : (size_t)0;
+  }();
+  update_phi_lds2_kernel<KPT, D, U, VL><<<grid, 64, lds + pad, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
