@@ -515,7 +515,10 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     // CALC_PROBS, beta.cc:145-160
     // (probs[] stays in registers between the two passes: the write-back into the ring slot and its re-read cost a
     // wave ~15 % of a trip -- in-kernel stamps, tools/beta_trace.sh -- and 16 registers do not change the occupancy)
-    float scratch = 0.0f, ppart = 0.0f, lo = 1.0f;
+    // the two sums of an edge (pi_a . pi_b and the probs, beta.cc:209-217) advance together: one wave per slot takes
+    // VLane's transposed two-row form (at wg 32 one swap per column pair for both chains; one tree for both sums)
+    float sums[2] = {0.0f, 0.0f};
+    float lo = 1.0f;
     f32x2 prr[HP];
 #pragma unroll
     for (int p = 0; p < HP; ++p) {
@@ -523,18 +526,31 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       if constexpr (FUSE) pb = pbn[p];
       else pb = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
       const f32x2 f = pa[p] * pb;
-      VLn::chain(scratch, f.x);
-      VLn::chain(scratch, f.y);
       const f32x2 pr = (y ? bk[p] : 1.0f - bk[p]) * f;
       prr[p] = pr;
-      VLn::chain(ppart, pr.x);
-      VLn::chain(ppart, pr.y);
+      if constexpr (W == 1) {
+        const float vx[2] = {f.x, pr.x}, vy[2] = {f.y, pr.y};
+        VLn::template chain_rows<2>(sums, vx);
+        VLn::template chain_rows<2>(sums, vy);
+      } else {
+        sums[0] += f.x;
+        sums[0] += f.y;
+        sums[1] += pr.x;
+        sums[1] += pr.y;
+      }
       const float m0 = fabsf(pr.x), m1 = fabsf(pr.y);
       lo = fminf(fminf(lo, m0 == 0.0f ? 1.0f : m0), m1 == 0.0f ? 1.0f : m1);  // an exact zero divides exactly
     }
-    float pi_sum = scratch, probs_sum = ppart;
+    float pi_sum = sums[0], probs_sum = sums[1];
     BETA_TRACE(8 + 4 * t + 2);
-    group_sum2(pi_sum, probs_sum);  // beta.cc:209-217
+    if constexpr (W == 1) {
+      float out2[2];
+      VLn::template tree_rows<2>(sums, out2);
+      pi_sum = out2[0];
+      probs_sum = out2[1];
+    } else {
+      group_sum2(pi_sum, probs_sum);  // beta.cc:209-217
+    }
     BETA_TRACE(8 + 4 * t + 3);
     const float w = y ? EPS : (1.0f - EPS);
     const float prob_0 = w * (1.0f - pi_sum);
