@@ -208,3 +208,17 @@ def test_persistent_streaming_update_phi(orc):
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "pair ok" in out.stdout
+
+
+def test_persistent_grid_update_phi(orc):
+    """update_phi_lds2_kernel with a persistent grid (opt-in, AMMSB_PHI_PERSIST=2: as many blocks as the chip holds, block b
+    takes virtual groups b, b + gridDim.x, ...): the groups keep their streams and nodes whichever block runs them."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (no fallback path exists)")
+    env = dict(os.environ, AMMSB_PHI_PERSIST="2")
+    cases = [(20000, 256, 32, 9000, 64), (20000, 256, 16, 8193, 32), (70000, 256, 16, 65535 + 900, 64)]
+    script = PAIR_CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "cases": repr(cases), "kernel": "lds2_kernel"}
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "pair ok" in out.stdout
