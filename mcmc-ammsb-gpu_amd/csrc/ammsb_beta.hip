@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     const uint32_t rel = t - tb;  // 0 .. 127 by construction
     const bool first = rel < 64u;
     const uint32_t src = first ? rel : rel - 64u;
-    const unsigned long long edge = first ? __shfl(kv, (int)src, 64) : __shfl(kv_next, (int)src, 64);
+    const unsigned long long edge = wave_lane_u64(first ? kv : kv_next, src);  // (t, tb are wave-uniform)
     *y = (((first ? ym : ym_next) >> src) & 1ull) != 0;
     return edge;
   };
@@ -448,6 +448,156 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     if (gs == 0 && tid == 0) a.fuse.phi_sum[shared_node] = sum;
   }
 
+  if constexpr (!FUSE && W == 1) {
+    // TWO edges per step where the slot's consecutive edges share their first end point (every edge of a node-strategy
+    // mini-batch does): the chains of edges t and t + 1 -- probs, two WG_SUMs each, reciprocal, division -- are issued
+    // together (a one-edge trip is a dependent chain of ~3 900 cycles for 301 vector instructions, in-kernel stamps),
+    // their four sums advance as one transposed four-row chain / tree (VLane::chain_rows<4> / tree_rows<4>), and the
+    // accumulators take edge t before edge t + 1: bit-identical to the one-edge loop.  The ring (D = 4 rows) is kept
+    // full: rows t .. t + 3 are in it or on their way whenever rows < t have been consumed.
+    uint32_t issued = 0;
+    auto fill = [&](uint32_t t) {
+#pragma unroll
+      for (uint32_t k = 0; k < D; ++k) {
+        if (issued < trips && issued < t + D) {
+          if (issued >= tb + 128) {  // the look-ahead leaves the two key windows: slide them (t >= tb + 64 here)
+            kv = kv_next;
+            ym = ym_next;
+            tb += 64;
+            kv_next = load_keys(tb + 64, &ym_next);
+          }
+          request(issued);
+          ++issued;
+        }
+      }
+    };
+    auto wait_rows = [&](uint32_t behind) {  // rows up to the ones consumed now have landed; `behind` rows may still fly
+      if (behind >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES) : "memory");
+      else if (behind == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    uint32_t t = 0;
+    while (t < trips) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots of rows < t have been read for the last time
+      BETA_TRACE(8 + 4 * (t / 2));
+      fill(t);
+      bool y0, y1 = false;
+      const unsigned long long e0 = key_of(t, &y0);
+      y0 = __builtin_amdgcn_readfirstlane((int)y0) != 0;
+      const uint32_t u0 = __builtin_amdgcn_readfirstlane((uint32_t)(e0 >> 32));
+      bool pair = t + 1 < trips;
+      if (pair) {
+        const unsigned long long e1 = key_of(t + 1, &y1);
+        y1 = __builtin_amdgcn_readfirstlane((int)y1) != 0;
+        pair = __builtin_amdgcn_readfirstlane((uint32_t)(e1 >> 32)) == u0;
+      }
+      BETA_TRACE(8 + 4 * (t / 2) + 1);
+      wait_rows(issued - (t + (pair ? 2u : 1u)));
+      BETA_TRACE(8 + 4 * (t / 2) + 2);
+      if (u0 != cur_u) {
+        const float* ra = rpm_row(a.pi, u0);
+#pragma unroll
+        for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[tid + 2 * L * p], ra[tid + 2 * L * p + L]};
+        // the loads are waited for HERE, inside the branch: left pending, hipcc's wait-count pass puts a vmcnt(0) in
+        // front of pa's first use after the join -- on every trip, whether the branch was taken or not -- which
+        // drains the rows in flight (the one-edge loop had exactly that until round 3: its ring never ran ahead)
+#pragma unroll
+        for (int p = 0; p < HP; ++p) asm volatile("" : "+v"(pa[p].x), "+v"(pa[p].y));
+        cur_u = u0;
+      }
+      const float* row0 = ring + (t % D) * KW;
+      if (pair) {
+        const float* row1 = ring + ((t + 1) % D) * KW;
+        float sums[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // pi_a . pi_b and probs of edge t, of edge t + 1
+        float lo0 = 1.0f, lo1 = 1.0f;
+        f32x2 pr0[HP], pr1[HP];
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 b0 = f32x2{row0[ln + 128 * p], row0[ln + 128 * p + 64]};
+          const f32x2 b1 = f32x2{row1[ln + 128 * p], row1[ln + 128 * p + 64]};
+          const f32x2 f0 = pa[p] * b0, f1 = pa[p] * b1;
+          pr0[p] = (y0 ? bk[p] : 1.0f - bk[p]) * f0;
+          pr1[p] = (y1 ? bk[p] : 1.0f - bk[p]) * f1;
+          const float vx[4] = {f0.x, pr0[p].x, f1.x, pr1[p].x}, vy[4] = {f0.y, pr0[p].y, f1.y, pr1[p].y};
+          VLn::template chain_rows<4>(sums, vx);
+          VLn::template chain_rows<4>(sums, vy);
+          const float m00 = fabsf(pr0[p].x), m01 = fabsf(pr0[p].y), m10 = fabsf(pr1[p].x), m11 = fabsf(pr1[p].y);
+          lo0 = fminf(fminf(lo0, m00 == 0.0f ? 1.0f : m00), m01 == 0.0f ? 1.0f : m01);  // an exact zero divides exactly
+          lo1 = fminf(fminf(lo1, m10 == 0.0f ? 1.0f : m10), m11 == 0.0f ? 1.0f : m11);
+        }
+        float tot[4];
+        VLn::template tree_rows<4>(sums, tot);  // beta.cc:209-217, both edges
+        BETA_TRACE(8 + 4 * (t / 2) + 3);
+        const float w0 = y0 ? EPS : (1.0f - EPS), w1 = y1 ? EPS : (1.0f - EPS);
+        const float ps0 = tot[1] + w0 * (1.0f - tot[0]), ps1 = tot[3] + w1 * (1.0f - tot[2]);
+        // CALC_GRADS, beta.cc:161-171: edge t, then edge t + 1
+        const bool fast0 = lo0 >= kProbsLo && in_range(ps0, kPsumLo, kPsumHi);
+        const bool fast1 = lo1 >= kProbsLo && in_range(ps1, kPsumLo, kPsumHi);
+        if (fast0 && fast1) {
+          const float r0 = exact_rcp(ps0), r1 = exact_rcp(ps1);
+          const f32x2 s0 = f32x2{ps0, ps0}, s1 = f32x2{ps1, ps1}, q0 = f32x2{r0, r0}, q1 = f32x2{r1, r1};
+#pragma unroll
+          for (int p = 0; p < HP; ++p) {
+            const f32x2 g0 = div_exact3(pr0[p], s0, q0), g1 = div_exact3(pr1[p], s1, q1);
+            acc0[p] += g0 * (y0 ? noo[p] : d0n[p]);
+            acc1[p] += g0 * (y0 ? d1l[p] : noo[p]);
+            acc0[p] += g1 * (y1 ? noo[p] : d0n[p]);
+            acc1[p] += g1 * (y1 ? d1l[p] : noo[p]);
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < HP; ++p) {
+            const f32x2 g0 = f32x2{pr0[p].x / ps0, pr0[p].y / ps0};
+            acc0[p] += g0 * (y0 ? noo[p] : d0n[p]);
+            acc1[p] += g0 * (y0 ? d1l[p] : noo[p]);
+            const f32x2 g1 = f32x2{pr1[p].x / ps1, pr1[p].y / ps1};
+            acc0[p] += g1 * (y1 ? noo[p] : d0n[p]);
+            acc1[p] += g1 * (y1 ? d1l[p] : noo[p]);
+          }
+        }
+        t += 2;
+      } else {
+        float sums[2] = {0.0f, 0.0f};
+        float lo = 1.0f;
+        f32x2 prr[HP];
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 pb = f32x2{row0[ln + 128 * p], row0[ln + 128 * p + 64]};
+          const f32x2 f = pa[p] * pb;
+          const f32x2 pr = (y0 ? bk[p] : 1.0f - bk[p]) * f;
+          prr[p] = pr;
+          const float vx[2] = {f.x, pr.x}, vy[2] = {f.y, pr.y};
+          VLn::template chain_rows<2>(sums, vx);
+          VLn::template chain_rows<2>(sums, vy);
+          const float m0 = fabsf(pr.x), m1 = fabsf(pr.y);
+          lo = fminf(fminf(lo, m0 == 0.0f ? 1.0f : m0), m1 == 0.0f ? 1.0f : m1);
+        }
+        float tot[2];
+        VLn::template tree_rows<2>(sums, tot);
+        const float w = y0 ? EPS : (1.0f - EPS);
+        const float probs_sum = tot[1] + w * (1.0f - tot[0]);
+        if (lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+          const float rps = exact_rcp(probs_sum);
+          const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
+#pragma unroll
+          for (int p = 0; p < HP; ++p) {
+            const f32x2 f = div_exact3(prr[p], psum2, rps2);
+            acc0[p] += f * (y0 ? noo[p] : d0n[p]);
+            acc1[p] += f * (y0 ? d1l[p] : noo[p]);
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < HP; ++p) {
+            const f32x2 f = f32x2{prr[p].x / probs_sum, prr[p].y / probs_sum};
+            acc0[p] += f * (y0 ? noo[p] : d0n[p]);
+            acc1[p] += f * (y0 ? d1l[p] : noo[p]);
+          }
+        }
+        t += 1;
+      }
+    }
+  } else {
   for (uint32_t t = 0; t < D - 1 && t < trips; ++t) request(t);
   BETA_TRACE(3);
   for (uint32_t t = 0; t < trips; ++t) {
@@ -509,6 +659,8 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       const float* ra = rpm_row(a.pi, u);
 #pragma unroll
       for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[tid + 2 * L * p], ra[tid + 2 * L * p + L]};
+#pragma unroll
+      for (int p = 0; p < HP; ++p) asm volatile("" : "+v"(pa[p].x), "+v"(pa[p].y));  // (waited for inside the branch, see above)
       cur_u = u;
     }
 
@@ -576,6 +728,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     }
   }
 
+  }
   BETA_TRACE(4);
   float* out = a.partials + (uint64_t)gs * 2 * K;
 #pragma unroll

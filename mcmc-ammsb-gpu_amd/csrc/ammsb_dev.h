@@ -486,6 +486,15 @@ struct VLane {
   static constexpr int PER = 64 / VL;  // virtual columns per physical column: draw j belongs to physical column j / PER
 };
 
+// value of `v` in lane `src` of the wave, for a wave-UNIFORM src (0 .. 63): two v_readlane_b32 with a scalar lane select
+// instead of the ds_bpermute round trips of __shfl (which cannot know that the index is uniform)
+__device__ __forceinline__ unsigned long long wave_lane_u64(unsigned long long v, uint32_t src) {
+  const int s = __builtin_amdgcn_readfirstlane((int)src);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), s);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // ----------------------------------------------------------------- virtual group sum (any K / L)
 // The generic kernels (the shapes no specialised kernel takes: more columns per reference work-item than fit a lane's
 // registers -- K = 1024 at the reference's default work-group size 32 for the gradient, K = 4096 at 32 for all three)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
     const uint32_t rel = t - tb;  // 0 .. 127 by construction
     const bool first = rel < 64u;
     const uint32_t src = first ? rel : rel - 64u;
-    const unsigned long long key = first ? __shfl(kv, (int)src, 64) : __shfl(kv_next, (int)src, 64);
+    const unsigned long long key = wave_lane_u64(first ? kv : kv_next, src);  // (t, tb are wave-uniform)
     *y = (((first ? ym : ym_next) >> src) & 1ull) != 0;
     return key;
   };

@@ -50,11 +50,13 @@ print(pr.ctx.kernel_names()["beta_grads"], "edges", ne)
 print("constants (theta reciprocals)  +%6d" % (t[1] - t[0]))
 print("two key windows loaded+probed  +%6d" % (t[2] - t[1]))
 print("first requests issued          +%6d" % (t[3] - t[2]))
-prev = t[3]
-trips = int((t[8:248:4] > 0).sum())
-for k in range(min(trips, 12)):
+# (the one-wave, separate-update_pi form reduces two edges per step and does not stamp slot 3 = "first requests")
+steps = int((t[8:248:4] > 0).sum())
+prev = t[2]
+for k in range(min(steps, 16)):
     a, b, c, d = t[8 + 4 * k: 12 + 4 * k]
-    print("  trip %2d: lgkm +%5d | request+row landed +%5d | probs pass +%5d | two WG_SUMs +%5d" % (k, a - prev, b - a, c - b, d - c))
-    prev = d
-print("trips", trips, "loop total", t[4] - t[3], "per trip", (t[4] - t[3]) // max(trips, 1), "| whole wave", t[4] - t[0])
+    tail = ("| probs + four sums +%5d" % (d - c)) if d > c else ""
+    print("  step %2d: since the last stamp +%5d | requests + keys +%5d | wait for rows +%5d %s" % (k, a - prev, b - a, c - b, tail))
+    prev = d if d > c else c
+print("steps", steps, "| whole wave", t[4] - t[0], "cycles")
 PY
