@@ -155,16 +155,28 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
   const uint32_t trips = gs < n_edges ? (n_edges - gs + a.P - 1) / a.P : 0;  // wave-uniform
   const float cm1 = (float)(a.call_count - 1), cc = (float)a.call_count;
 
-  auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
+  // lane i of a window holds the key, the link bit and the running mean (perplexity.cc:139-156) of trip tb + i: nothing
+  // is LOADED inside the trip loop but the rows.  (The mean used to be read where it is used, by lane 0 behind the row
+  // requests: hipcc's wait-count pass put a vmcnt(0) in front of its first use on every trip, which drained the next
+  // edge's rows -- the ring never ran ahead; found in the disassembly in round 3, as in the gradient kernel.)
+  auto load_keys = [&](uint32_t tb, unsigned long long* ymask, float* mean) -> unsigned long long {
     const bool ok = tb + l < trips;
     const uint64_t e = (uint64_t)a.edge_begin + gs + (uint64_t)(tb + l) * a.P;
     const unsigned long long key = a.edges[ok ? e : a.edge_begin];
+    *mean = a.ppx_per_edge[ok ? e : a.edge_begin];
     *ymask = __ballot(set_has(a.set, key));  // used as stored: no canonicalisation (perplexity.cc:45-47)
     return key;
   };
   uint32_t tb = 0;
   unsigned long long ym = 0, ym_next = 0;
-  unsigned long long kv = load_keys(0, &ym), kv_next = load_keys(64, &ym_next);
+  float pm = 0.0f, pm_next = 0.0f;
+  unsigned long long kv = load_keys(0, &ym, &pm), kv_next = load_keys(64, &ym_next, &pm_next);
+  auto mean_of = [&](uint32_t t) -> float {
+    const uint32_t rel = t - tb;
+    const bool first = rel < 64u;
+    const int src = __builtin_amdgcn_readfirstlane((int)(first ? rel : rel - 64u));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(first ? pm : pm_next), src));
+  };
   auto key_of = [&](uint32_t t, bool* y) -> unsigned long long {
     const uint32_t rel = t - tb;  // 0 .. 127 by construction
     const bool first = rel < 64u;
@@ -200,8 +212,9 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
       if (t + D - 1 >= tb + 128) {  // the look-ahead leaves the two key windows: slide them
         kv = kv_next;
         ym = ym_next;
+        pm = pm_next;
         tb += 64;
-        kv_next = load_keys(tb + 64, &ym_next);
+        kv_next = load_keys(tb + 64, &ym_next, &pm_next);
       }
       request(t + D - 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 2 * PIECES) : "memory");  // edge t landed, t+1, t+2 in flight
@@ -234,9 +247,10 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
       s += tt * u1;
     }
     if (s < 1.0e-30f) s = 1.0e-30f;
+    const float mean_old = mean_of(t);
     if (l == 0) {  // perplexity.cc:139-156
       const uint64_t pos = (uint64_t)a.edge_begin + gs + (uint64_t)t * a.P;
-      float ppx = a.ppx_per_edge[pos];
+      float ppx = mean_old;
       float m = ppx * cm1;
       m = m + s;
       ppx = m / cc;
