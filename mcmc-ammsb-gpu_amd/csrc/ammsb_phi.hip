@@ -91,8 +91,9 @@ __device__ __forceinline__ PhiStep phi_step(const PhiArgs& a) {
 // FULL: K == L * KPT, so no column guard is needed anywhere.  Loads are always unconditional (row
 // and column indices are clamped instead of predicated): a predicated load turns into a branch plus a
 // full vmcnt(0) drain per element, which serialises the row stream.
-template <int L, int KPT, int DEPTH, bool FULL>
+template <int L, int KPT, int DEPTH, bool FULL, bool ONE = false>
 __global__ __launch_bounds__(Group<L>::BLOCK) void update_phi_kernel(const PhiArgs a) {
+  if constexpr (ONE) __builtin_assume(a.pi.num_blocks == 1);  // (see update_phi_lds2_kernel; short rows at wg 32 / 64 only)
   using Grp = Group<L>;
   extern __shared__ uint32_t s_nb_all[];  // [PER_BLOCK][n]: neighbour id | link bit << 31
   __shared__ ZigTables zig;
@@ -419,8 +420,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // VL = 32 (only with W == 1): the reference work-group size is 32, not 64 -- the node still gets the whole wave and
 // every lane its 64-strided columns; the WG_SUM chain / tree and the stream-to-column map follow the 32 virtual lanes
 // (VLane<32>, ammsb_dev.h).  K = 1024 at the reference's default phi_wg_size (main.cc:61) takes this form.
-template <int KPT, int W, int D = 2, int NB = 1, int VL = 64>
+template <int KPT, int W, int D = 2, int NB = 1, int VL = 64, bool ONE = false>
 __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT <= 4 ? AMMSB_PHI_WPE4 : KPT <= 8 ? AMMSB_PHI_WPE8 : KPT <= 16 ? 3 : 2))) void update_phi_lds_kernel(const PhiArgs a) {
+  if constexpr (ONE) __builtin_assume(a.pi.num_blocks == 1);  // (see update_phi_lds2_kernel)
   static_assert(NB == 1 || W == 1, "several nodes per block only for one-wave nodes");
   static_assert(VL == 64 || W == 1, "virtual half-wave lanes only for one-wave nodes");
   using VLn = VLane<VL>;
@@ -693,8 +695,12 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
 // chains per wave.  Every value is computed by the same operations in the same order as in the single-row kernel:
 // results are bit-identical (same tests).  Needs an even n; odd n takes the single-row kernel.
 // VL = 32: the reference work-group size 32 in the same one-wave-per-node layout (see update_phi_lds_kernel).
-template <int KPT, int D, int U, int VL = 64>
+// ONE: pi is a single block (every configuration of interest on a 288 GB device; the launcher checks).  Told to the
+// compiler as an assumption, which folds the block look-up -- a 32-bit division, a table read and the registers that
+// keep them alive -- out of every rpm_row() of the kernel: -3 % per launch at K = 256, -10 % at K = 32 (same-box A/B).
+template <int KPT, int D, int U, int VL = 64, bool ONE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT == 4 ? 4 : 3))) void update_phi_lds2_kernel(const PhiArgs a) {
+  if constexpr (ONE) __builtin_assume(a.pi.num_blocks == 1);
   constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
   using VLn = VLane<VL>;
   constexpr int KV = KPT * VLn::PER;  // columns (= normals) per virtual lane
@@ -1857,8 +1863,10 @@ int launch_phi_stream(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipSt
 template <int KPT, int D, int U, int VL = 64>
 int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t lds = (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + sizeof(uint32_t) * a.n;
-  static const std::string name = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d, %d>", KPT, D, U, VL);
-  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
+  const bool one = a.pi.num_blocks == 1;
+  static const std::string name1 = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d, %d, true>", KPT, D, U, VL);
+  static const std::string name0 = ammsb_kname("update_phi_lds2_kernel<%d, %d, %d, %d, false>", KPT, D, U, VL);
+  ctx->kernel_name[AMMSB_KN_PHI] = (one ? name1 : name0).c_str();
   // AMMSB_PHI_PERSIST=1|2|3 (A/B runs): a persistent grid for launches of more groups than the chip holds at once
   // (1: resident slots when the excess over whole rounds is small, else the groups spread evenly over the fewest rounds;
   // 2: always the resident slots; 3: always the even spread).  Measured equal or slightly slower than one block per
@@ -1869,7 +1877,7 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
   }();
   static const int per_cu = [] {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, update_phi_lds2_kernel<KPT, D, U, VL>, 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, update_phi_lds2_kernel<KPT, D, U, VL, true>, 64,
                                                      (size_t)(D + (KPT == U ? 0 : 1)) * sizeof(float) * 64 * KPT + 128) != hipSuccess || v < 1)
       v = 0;
     return v;
@@ -1885,7 +1893,8 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
     const char* f = getenv("AMMSB_PHI_LDS_PAD");
     return f ? (size_t)atoi(f) : (size_t)0;
   }();
-  update_phi_lds2_kernel<KPT, D, U, VL><<<grid, 64, lds + pad, s>>>(a);
+  if (one) update_phi_lds2_kernel<KPT, D, U, VL, true><<<grid, 64, lds + pad, s>>>(a);
+  else update_phi_lds2_kernel<KPT, D, U, VL, false><<<grid, 64, lds + pad, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1893,9 +1902,12 @@ int launch_phi_lds2(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStre
 template <int KPT, int W, int D = 2, int NB = 1, int VL = 64>
 int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
   const size_t per_node = (size_t)W * (D + 1) * sizeof(float) * 64 * KPT + ((sizeof(uint32_t) * a.n + 15) & ~(size_t)15);
-  static const std::string name = ammsb_kname("update_phi_lds_kernel<%d, %d, %d, %d, %d>", KPT, W, D, NB, VL);
-  ctx->kernel_name[AMMSB_KN_PHI] = name.c_str();
-  update_phi_lds_kernel<KPT, W, D, NB, VL><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
+  const bool one = a.pi.num_blocks == 1;
+  static const std::string name1 = ammsb_kname("update_phi_lds_kernel<%d, %d, %d, %d, %d, true>", KPT, W, D, NB, VL);
+  static const std::string name0 = ammsb_kname("update_phi_lds_kernel<%d, %d, %d, %d, %d, false>", KPT, W, D, NB, VL);
+  ctx->kernel_name[AMMSB_KN_PHI] = (one ? name1 : name0).c_str();
+  if (one) update_phi_lds_kernel<KPT, W, D, NB, VL, true><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
+  else update_phi_lds_kernel<KPT, W, D, NB, VL, false><<<(n_groups + NB - 1) / NB, 64 * W * NB, per_node * NB, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1943,8 +1955,21 @@ int launch_phi(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t 
   constexpr int DEPTH = KPT >= 32 ? 2 : 4;
   const uint32_t blocks = (n_groups + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
   const size_t lds = sizeof(uint32_t) * Grp::PER_BLOCK * a.n;
-  static const std::string name_full = ammsb_kname("update_phi_kernel<%d, %d, %d, true>", L, KPT, DEPTH);
-  static const std::string name_part = ammsb_kname("update_phi_kernel<%d, %d, %d, false>", L, KPT, DEPTH);
+  if constexpr (KPT <= 2 && (L == 32 || L == 64)) {  // the latency-bound shapes (C1): the single-block form pays there
+    if (a.pi.num_blocks == 1) {
+      static const std::string name_full1 = ammsb_kname("update_phi_kernel<%d, %d, %d, true, true>", L, KPT, DEPTH);
+      static const std::string name_part1 = ammsb_kname("update_phi_kernel<%d, %d, %d, false, true>", L, KPT, DEPTH);
+      ctx->kernel_name[AMMSB_KN_PHI] = (a.K == (uint32_t)(L * KPT) ? name_full1 : name_part1).c_str();
+      if (a.K == (uint32_t)(L * KPT))
+        update_phi_kernel<L, KPT, DEPTH, true, true><<<blocks, Grp::BLOCK, lds, s>>>(a);
+      else
+        update_phi_kernel<L, KPT, DEPTH, false, true><<<blocks, Grp::BLOCK, lds, s>>>(a);
+      AMMSB_LAUNCH_CHECK(ctx);
+      return AMMSB_OK;
+    }
+  }
+  static const std::string name_full = ammsb_kname("update_phi_kernel<%d, %d, %d, true, false>", L, KPT, DEPTH);
+  static const std::string name_part = ammsb_kname("update_phi_kernel<%d, %d, %d, false, false>", L, KPT, DEPTH);
   ctx->kernel_name[AMMSB_KN_PHI] = (a.K == (uint32_t)(L * KPT) ? name_full : name_part).c_str();
   if (a.K == (uint32_t)(L * KPT))
     update_phi_kernel<L, KPT, DEPTH, true><<<blocks, Grp::BLOCK, lds, s>>>(a);
