@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -373,7 +374,9 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
             (st[:, 2] >= st[:, 1]) & (st[:, 1] >= st[:, 0])
         if ok.any():
             d = lambda a, b: float((st[ok, b] - st[ok, a]).mean()) * 1e-9  # noqa: E731  (seconds)
-            fused = ", true" in names["beta_grads"]  # update_pi folded into the gradient kernel (<..., FUSE = true, ...>)
+            # update_pi folded into the gradient kernel: FUSE is the third template argument of both gradient kernels
+            mf = re.search(r"<\s*\d+,\s*\d+,\s*(true|false)", names["beta_grads"])
+            fused = bool(mf) and mf.group(1) == "true"
             nodes = m + 1
             b_phi = phi_bytes_per_node(K, n) * nodes
             b_pi = (8 * K + 8) * nodes

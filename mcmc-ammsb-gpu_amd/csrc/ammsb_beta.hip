@@ -72,8 +72,9 @@ __device__ __forceinline__ BetaStep beta_step(const BetaArgs& a) {
 
 // FUSE: update_pi folded in, as in beta_grads_lds_kernel<KPT, 1, true> below (which has the description): the rows come
 // from phi_vec, are normalised with update_pi_kernel<L, KPT>'s arithmetic as they are consumed, and are stored to pi.
-template <int L, int KPT, bool FUSE = false>
+template <int L, int KPT, bool FUSE = false, bool ONE = false>
 __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaArgs a) {
+  if constexpr (ONE) __builtin_assume(a.pi.num_blocks == 1);  // (pi is one block: see update_phi_lds2_kernel, ammsb_phi.hip)
   using Grp = Group<L>;
   __shared__ float aux[Grp::AUX];
   const int l = Grp::lane();
@@ -1157,12 +1158,18 @@ template <int L, int KPT>
 int launch_grads(ammsb_ctx* ctx, const BetaArgs& a, hipStream_t s) {
   using Grp = Group<L>;
   const uint32_t blocks = (a.P + Grp::PER_BLOCK - 1) / Grp::PER_BLOCK;
-  static const std::string name = ammsb_kname("beta_grads_kernel<%d, %d, false>", L, KPT);
-  static const std::string name_fused = ammsb_kname("beta_grads_kernel<%d, %d, true>", L, KPT);
+  static const std::string name = ammsb_kname("beta_grads_kernel<%d, %d, false, false>", L, KPT);
+  static const std::string name_fused = ammsb_kname("beta_grads_kernel<%d, %d, true, false>", L, KPT);
+  static const std::string name_fused1 = ammsb_kname("beta_grads_kernel<%d, %d, true, true>", L, KPT);
   ctx->kernel_name[AMMSB_KN_GRADS] = (a.fuse.phi_vec ? name_fused : name).c_str();
   if constexpr ((L == 32 || L == 64) && KPT <= 2) {  // the short-row shapes that take the fusion (beta_fuse_shape)
     if (a.fuse.phi_vec) {
-      beta_grads_kernel<L, KPT, true><<<blocks, Grp::BLOCK, 0, s>>>(a);
+      if (a.pi.num_blocks == 1) {  // (the launch-latency shapes, C1: the single-block instantiation pays there)
+        ctx->kernel_name[AMMSB_KN_GRADS] = name_fused1.c_str();
+        beta_grads_kernel<L, KPT, true, true><<<blocks, Grp::BLOCK, 0, s>>>(a);
+      } else {
+        beta_grads_kernel<L, KPT, true><<<blocks, Grp::BLOCK, 0, s>>>(a);
+      }
       AMMSB_LAUNCH_CHECK(ctx);
       return AMMSB_OK;
     }
