@@ -51,8 +51,11 @@ def functions(text):
 
 
 def trip_loop(insts):
-    """(start, end) index range of the innermost backward-branch loop holding an LDS-DMA load and a store."""
+    """(start, end) index range of the innermost backward-branch loop that holds the function's LAST LDS-DMA load (the
+    trip loop's row request; the fused form also fills its ring once, earlier, from a short loop of its own) and a store."""
     addr_to_idx = {a: i for i, (a, _, _) in enumerate(insts)}
+    dma = [i for i, (_, o, _) in enumerate(insts) if o.startswith("global_load_lds")]
+    last_dma = dma[-1] if dma else -1
     best = None
     for i, (a, op, args) in enumerate(insts):
         if not op.startswith("s_cbranch") and op != "s_branch":
@@ -68,7 +71,7 @@ def trip_loop(insts):
             continue
         j = addr_to_idx[target]
         body = insts[j:i + 1]
-        if any(o.startswith("global_load_lds") for _, o, _ in body) and any(o.startswith("global_store") for _, o, _ in body):
+        if j <= last_dma <= i and any(o.startswith("global_store") for _, o, _ in body):
             if best is None or (i - j) < (best[1] - best[0]):
                 best = (j, i)
     return best
