@@ -296,6 +296,9 @@ __device__ __forceinline__ bool set_has(const DevSet& set, uint64_t k) { return 
 // TTRowPartitionedMatrix_Row, mcmc/partitioned-alloc.h:22-29, with 64-bit offsets.
 
 __device__ __forceinline__ float* rpm_row(const ammsb_rpm& m, uint64_t row) {
+#ifdef AMMSB_RPM_SINGLE  // experiment builds only: every kernel without the multi-block path (what it costs where ONE is not used)
+  return reinterpret_cast<float*>(m.blocks[0]) + row * m.num_cols;
+#endif
   if (m.num_blocks == 1) return reinterpret_cast<float*>(m.blocks[0]) + row * m.num_cols;
   // Row indices are vertex ids (32 bits) and a block holds at most that many rows: a 32-bit division.  Written with
   // 64-bit operands this line was ~120 instructions at every call site (hipcc's 64-bit divide with its own "do both fit
