@@ -61,7 +61,13 @@ def parse():
     ap.add_argument("--ppx-calls", type=int, default=5)
     ap.add_argument("--extras", type=int, default=1,
                     help="one GPU: also time the workload at the reference's default work-group sizes (32) and, for C3, "
-                         "short C1 and C2 runs (small_configs)")
+                         "short C1 and C2 runs (small_configs) and BASELINE's largest configuration C5 (large_configs)")
+    ap.add_argument("--large", default=os.environ.get("AMMSB_BENCH_LARGE", "auto"), choices=["auto", "C5", "C5s", "none"],
+                    help="large_configs of the default run: C5 (N=10M, K=4096: ~2 min of host set-up, 164 GB of pi), its "
+                         "2M-vertex stand-in C5s, none; auto = C5 when HBM and host memory allow, else C5s")
+    ap.add_argument("--settle-s", type=float, default=1.5,
+                    help="seconds of untimed iterations BEFORE the warm-up steps: the package is at its power cap under "
+                         "update_phi and its power controller takes about a second to settle (profiles/README.md)")
     return ap.parse_args()
 
 
@@ -267,9 +273,10 @@ def phi_bytes_per_node(K, n):
     return 4 * K * (n + 2) + 68 * n + 8
 
 
-def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_calls):
+def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_calls, settle_s=0.0):
     """ppx latency, then `warmup` untimed and EXACTLY `steps` timed iterations of `lrn` (barrier + synchronize on both
     sides, max over ranks).  Returns the numbers of one bench record."""
+    from mcmc_ammsb_gpu_amd import gpu_state
     K, n = cfg.K, cfg.num_node_sample
 
     def sync():
@@ -277,6 +284,24 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- settle: untimed iterations until the package's power controller has reached its steady state (the same
+    # number of steps on every rank: decided by rank 0's clock, in whole chunks)
+    settle_steps = 0
+    if settle_s > 0:
+        chunk = 100 if m >= 32768 else 2000
+        t_s = time.perf_counter()
+        while True:
+            lrn.Run(chunk)
+            sync()
+            settle_steps += chunk
+            go = time.perf_counter() - t_s < settle_s and settle_steps < 20000
+            if world > 1:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+                dist.broadcast(flag, 0)
+                go = bool(flag.item())
+            if not go:
+                break
 
     # ---- perplexity latency (mean of ppx_calls, after one untimed call)
     ppx, ppx_ms = None, None
@@ -311,6 +336,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
     first_step = phi.count_calls + 1
     edges_before = lrn.edges_done
     sync()
+    state_before = gpu_state.read(torch.cuda.current_device())
     prof = None
     if os.environ.get("AMMSB_BENCH_PROFILE"):  # development aid: cProfile of the enqueue side of the timed region
         import cProfile
@@ -325,6 +351,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
         pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(14)
     sync()
     dt = time.perf_counter() - t0
+    state_after = gpu_state.read(torch.cuda.current_device())
     phi.update_phi = orig
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -451,7 +478,29 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
                         "achieved_GBps": round(b_ppx / (ppx_ms * 1e-3) / 1e9, 1),
                         "frac": round(b_ppx / (ppx_ms * 1e-3) / 1e9 / 8000.0, 4),
                         "note": "whole HeldoutPerplexity() call (kernel + reduction + the 32-byte read-back), host-timed"}
-    return {"value": edges_done / dt, "ms_per_step": dt * 1e3 / steps, "dt": dt, "edges_done": int(edges_done),
+    # ---- the shader clock the chip holds UNDER this workload: a few more (untimed) steps with the probe's idle waves
+    # beside them on their own stream (ammsb_clock_probe) -- a roofline fraction is read against the clocks it ran at
+    device_state = gpu_state.summarize(state_before, state_after)
+    try:
+        from mcmc_ammsb_gpu_amd import ops as _ops
+        probe = _ops.ClockProbe(lrn.ctx, 64)
+        n_probe = 12 if m >= 32768 else 60
+        lrn.Run(n_probe // 3)
+        probe.launch(600)
+        lrn.Run(n_probe - n_probe // 3)
+        clk = probe.read()
+        sync()
+        device_state["shader_clock_under_load_mhz"] = clk["mhz"]
+        device_state["shader_clock_per_xcd_mhz"] = clk["mhz_per_xcd"]
+        device_state["shader_clock_how"] = ("s_memtime / s_memrealtime of idle probe waves on a second stream beside %d "
+                                            "untimed steps right after the timed window" % n_probe)
+    except Exception as e:  # a measurement aid: never lose the bench line over it
+        device_state["shader_clock_under_load_mhz"] = None
+        device_state["shader_clock_how"] = "probe failed: %r" % (e,)
+    if roofline is not None:
+        roofline["device_state"] = device_state
+    return {"settle_steps": settle_steps, "device_state": device_state,
+            "value": edges_done / dt, "ms_per_step": dt * 1e3 / steps, "dt": dt, "edges_done": int(edges_done),
             "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "step_classes": step_classes,
             "value_per_class": value_per_class, "roofline": roofline, "ppx_ms": ppx_ms, "ppx": ppx,
             "kernel_names": names}
@@ -464,7 +513,9 @@ def sub_record(r, cfg, steps, warmup, loop):
             "value_per_class": r["value_per_class"], "step_classes": r["step_classes"],
             "phi_wg": cfg.phi_wg_size, "beta_wg": cfg.beta_wg_size, "ppx_wg": cfg.ppx_wg_size,
             "kernels_dispatched": r["kernel_names"],
-            "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "step", "kernels")},
+            "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "step", "kernels",
+                                                "device_state")},
+            "settle_steps": r.get("settle_steps", 0),
             "ppx_eval_ms": r["ppx_ms"], "loop": loop, "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"]}
 
 
@@ -523,10 +574,12 @@ def main():
                    pick_wg(K, args.beta_wg, 16), pick_wg(K, args.ppx_wg, 16), use_graph)
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
+    lrn_E, lrn_H = int(ds.E), int(ds.heldout_edges.size)
     graphs = lrn.loop is not None
     note("learner ready (%s loop)" % ("device-descriptor" if graphs else "eager"))
 
-    r = measure(args, lrn, cfg, m, args.steps, args.warmup, world, dist, torch, args.workload, args.ppx_calls)
+    r = measure(args, lrn, cfg, m, args.steps, args.warmup, world, dist, torch, args.workload, args.ppx_calls,
+                settle_s=args.settle_s)
     dt, edges_done, roofline = r["dt"], r["edges_done"], r["roofline"]
 
     cpu = None
@@ -564,25 +617,35 @@ def main():
         except Exception as e:
             ref_wg = {"error": repr(e)}
 
-    # ---- the small configurations of BASELINE.json (launch-latency territory), each with its own graph and Learner
+    # ---- the other single-GPU configurations of BASELINE.json, each with its own graph and Learner: the small ones
+    # (launch-latency territory) and, further down, the largest (C5: N = 10M, K = 4096, degree 64)
+    def other_config(name, st_n, wu_n, ppx_n, settle):
+        t_cfg = time.perf_counter()
+        N2, K2, m2, n2, deg2, kt2 = WORKLOADS[name]
+        e2 = hostlib.generate_graph(N2, kt2, deg2, seed=20260101)
+        ds2 = hostlib.Dataset.robust(N2, e2, heldout_ratio=0.01, rand_seed=1)
+        c2 = make_cfg(K2, m2, n2, pick_wg(K2, 0, 16), pick_wg(K2, 0, 16), pick_wg(K2, 0, 16), use_graph)
+        l2 = Learner(c2, ds2, rank=0, world_size=1)
+        setup2 = time.perf_counter() - t_cfg
+        note("%s: learner ready after %.1f s" % (name, setup2))
+        r2 = measure(args, l2, c2, m2, st_n, wu_n, 1, dist, torch, name, ppx_n, settle_s=settle)
+        rec = sub_record(r2, c2, st_n, wu_n, loop_form(l2.loop is not None))
+        rec["workload"] = "%s: synthetic a-MMSB graph N=%d avg-degree=%d K=%d mini-batch=%d n=%d strategy=Node" \
+            % (name, N2, deg2, K2, m2, n2)
+        rec["E"], rec["heldout_edges"], rec["setup_s"] = int(ds2.E), int(ds2.heldout_edges.size), round(setup2, 1)
+        rec["pi_bytes"] = 4 * N2 * K2
+        l2.close()
+        del l2, ds2, e2
+        torch.cuda.empty_cache()
+        note("%s: %.4f ms per step" % (name, rec["ms_per_step"]))
+        return rec
+
     small = None
     if rank == 0 and world == 1 and args.extras and args.workload == "C3":
         small = {}
         for name, st_small in (("C1", 3000), ("C2", 2000)):
             try:
-                N2, K2, m2, n2, deg2, kt2 = WORKLOADS[name]
-                e2 = hostlib.generate_graph(N2, kt2, deg2, seed=20260101)
-                ds2 = hostlib.Dataset.robust(N2, e2, heldout_ratio=0.01, rand_seed=1)
-                c2 = make_cfg(K2, m2, n2, pick_wg(K2, 0, 16), pick_wg(K2, 0, 16), pick_wg(K2, 0, 16), use_graph)
-                l2 = Learner(c2, ds2, rank=0, world_size=1)
-                r2 = measure(args, l2, c2, m2, st_small, 200, 1, dist, torch, name, 2)
-                small[name] = sub_record(r2, c2, st_small, 200, loop_form(l2.loop is not None))
-                small[name]["workload"] = "%s: synthetic a-MMSB graph N=%d avg-degree=%d K=%d mini-batch=%d n=%d strategy=Node" \
-                    % (name, N2, deg2, K2, m2, n2)
-                l2.close()
-                del l2, ds2, e2
-                torch.cuda.empty_cache()
-                note("%s: %.4f ms per step" % (name, small[name]["ms_per_step"]))
+                small[name] = other_config(name, st_small, 200, 2, 0.5)
             except Exception as e:
                 small[name] = {"error": repr(e)}
 
@@ -593,7 +656,36 @@ def main():
         except Exception as e:
             cpp = {"error": repr(e)}
 
+    # ---- BASELINE.json configs[4], C5: N = 10M, K = 4096, average degree 64 -- pi is 164 GB in ONE allocation (the
+    # reference cannot address it: 32-bit row offsets, partitioned-alloc.h:24-28; and its perplexity kernel would
+    # allocate 52 GB of scratch, perplexity.cc:245-247).  About two minutes of host set-up (graph, cuckoo sets, CSR).
+    large = None
+    if rank == 0 and world == 1 and args.extras and args.workload == "C3" and args.large != "none":
+        del ds, edges
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        which = args.large
+        if which == "auto":
+            free_hbm, _ = torch.cuda.mem_get_info()
+            try:
+                host_free = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+            except (ValueError, OSError):
+                host_free = 0
+            which = "C5" if free_hbm > 215e9 and host_free > 48e9 else "C5s"
+            note("large_configs: %s (free HBM %.0f GB, free host memory %.0f GB)" % (which, free_hbm / 1e9, host_free / 1e9))
+        large = {}
+        try:
+            large[which] = other_config(which, 40, 6, 3, 1.0)
+            if which != "C5":
+                large[which]["stand_in"] = ("C5s = C5's rows (K = 4096, mini-batch 65536) over 2M vertices at degree 32: "
+                                            "taken because this box could not hold C5 (N = 10M: 164 GB of pi)")
+        except Exception as e:
+            large[which] = {"error": repr(e)}
+        ds = edges = None
+
     if rank == 0:
+        E_main, H_main = int(lrn_E), int(lrn_H)
         out = {
             "metric": "mini-batch edges/s (SG-MCMC a-MMSB learner loop)",
             "value": edges_done / dt,
@@ -610,7 +702,7 @@ def main():
             "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: %s backend, ranks share GPUs)" % backend,
             "config": {"workload": "%s: synthetic a-MMSB graph N=%d avg-degree=%d K=%d mini-batch=%d n=%d strategy=Node"
                                    % (args.workload, N, deg, K, m, n),
-                       "E": int(ds.E), "heldout_edges": int(ds.heldout_edges.size),
+                       "E": E_main, "heldout_edges": H_main,
                        "phi_wg": cfg.phi_wg_size, "beta_wg": cfg.beta_wg_size, "ppx_wg": cfg.ppx_wg_size,
                        "sampling": "host(rand_r): the reference's stream" if args.host_sampling else
                                    "device: same distribution as sample.cc, NOT its rand_r stream (same seed does not "
@@ -631,6 +723,10 @@ def main():
             "cpu_baseline": cpu,
             "reference_default_wg": ref_wg,
             "small_configs": small,
+            "large_configs": large,
+            "settle": {"seconds": args.settle_s, "steps": r.get("settle_steps", 0),
+                       "why": "untimed iterations in front of the warm-up steps: update_phi holds the package at its power "
+                              "cap and the power controller needs about a second to settle (profiles/README.md)"},
             "cpp_dropin": cpp,
         }
         print(json.dumps(out))

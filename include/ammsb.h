@@ -322,6 +322,13 @@ int ammsb_loop_step_stamps(ammsb_loop* loop, uint32_t first_step, uint32_t n_ste
  * the large launches take. */
 const char* ammsb_last_kernel_name(const ammsb_ctx* ctx, int which);
 
+/* Measurement aid (no reference counterpart): n_blocks one-wave blocks each idle for spin_us microseconds of the
+ * 100 MHz device wall clock and write {shader cycles, wall ticks, XCC id} of that interval to out[3 * block ..]
+ * (device memory, 24 bytes per block).  cycles / ticks x 100 MHz = the shader clock that XCD held meanwhile -- launched
+ * on a second stream beside a kernel under test it reads the clock the chip holds UNDER that load (the chip lowers
+ * its clock under load and devices differ: a roofline fraction is read against the clock it was taken at). */
+int ammsb_clock_probe(ammsb_ctx* ctx, uint64_t* out, uint32_t n_blocks, uint32_t spin_us, void* stream);
+
 /* ---- wg_* primitives (test entry points; kernels of algorithm/{sum,normalize,sort}.cc) ---- */
 /* WG_SUM_KERNEL_TT, sum.cc:44-52: out[r] = WG_SUM(in + r*len, len) with `wg` lanes (any wg in [1,1024]) */
 int ammsb_wg_sum_f32(ammsb_ctx* ctx, const float* in, float* out, uint32_t rows, uint32_t len, uint32_t wg,

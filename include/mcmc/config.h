@@ -62,8 +62,11 @@ struct Config {
 
   SampleStrategy strategy;
 
-  // Accepted for source compatibility.  All four values select the register-resident work-group
-  // kernel; THREAD (the reference's CPU-device shape) has no GPU counterpart here.
+  // The three work-group modes run the same arithmetic on the same lane / column / stream map (phi.cc:214-606) and
+  // select the one HIP kernel family (a warning names the mode when it is not NAIVE).  PHI_NODE_PER_THREAD -- the
+  // reference's CPU-device shape, one RNG stream per node -- is refused by PhiUpdater (std::invalid_argument).
+  // phi_vector_width > 1 changes results in the reference (Floatn column ownership) and is NOT reproduced: the
+  // operators warn and compute width 1.  sum_grads_vector_width has no numerical effect (beta.cc:39-49).
   PhiUpdaterMode phi_mode;
   bool phi_probs_shared;
   bool phi_grads_shared;

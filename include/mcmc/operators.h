@@ -309,6 +309,7 @@ class PerplexityCalculator {
   OpenClSet* edgeSet_;
   clcuda::Buffer<Float> ppx_per_edge_;
   clcuda::Buffer<ammsb_ppx_sums> sums_;
+  std::shared_ptr<ammsb_ppx_sums> host_sums_;  // host-mapped pinned memory the kernel writes operator()()'s result into
   uint32_t count_calls_, local_;
   uint64_t t_ppx_ = 0;
 };

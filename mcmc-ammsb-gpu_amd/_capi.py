@@ -110,6 +110,7 @@ SIGNATURES = {
     "ammsb_wg_sort_f32": [_vp, _vp, _vp, _u32, _vp],
     "ammsb_randn_fill": [_vp, _vp, _u32, _u32, _vp, _vp],
     "ammsb_rpm_fetch": [_vp, _P(Rpm), _u64, _u64, _vp, _vp],
+    "ammsb_clock_probe": [_vp, _vp, _u32, _u32, _vp],
 }
 _OTHER_RES = {"ammsb_strerror": C.c_char_p, "ammsb_last_error": C.c_char_p, "ammsb_last_kernel_name": C.c_char_p,
               "ammsb_eps_t": C.c_float,

@@ -29,8 +29,19 @@ __device__ unsigned long long g_beta_trace[256];
 extern "C" int ammsb_debug_trace_beta(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_beta_trace), sizeof(unsigned long long) * (n < 256 ? n : 256)) == hipSuccess ? 0 : -2;
 }
+// per-block record: [block][0..1] shader clock at start / end, [2..3] 100 MHz wall clock at start / end, [4] HW_ID | XCC_ID << 32
+__device__ unsigned long long g_beta_blk[4096 * 5];
+#define BETA_BLK(end) do { if (threadIdx.x == 0 && blockIdx.x < 4096) { \
+    g_beta_blk[blockIdx.x * 5 + (end)] = __builtin_readcyclecounter(); \
+    g_beta_blk[blockIdx.x * 5 + 2 + (end)] = __builtin_amdgcn_s_memrealtime(); \
+    if (!(end)) g_beta_blk[blockIdx.x * 5 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
+                                                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } while (0)
+extern "C" int ammsb_debug_blocks_beta(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_beta_blk), sizeof(unsigned long long) * 5 * (n_blocks < 4096 ? n_blocks : 4096)) == hipSuccess ? 0 : -2;
+}
 #else
 #define BETA_TRACE(slot) do { } while (0)
+#define BETA_BLK(end) do { } while (0)
 #endif
 
 namespace {
@@ -42,7 +53,7 @@ struct BetaArgs {
   DevSet set;  // (ammsb_dev.h: the descriptor + the modulo magic)
   const uint64_t* edges;
   float* partials;   // [P, 2K]
-  float* theta_sum;  // [K]
+  const float4* coef;  // [K] per-column constants of CALC_GRADS (theta_coef below): {beta_k, d0n, d1l, noo}
   uint32_t edge_begin, edge_end, P, K;
   float epsilon;
   const ammsb_step_desc* desc;  // non-null (captured graph): edges [0, desc->n_edges), P = min(n_edges, P)
@@ -70,6 +81,27 @@ __device__ __forceinline__ BetaStep beta_step(const BetaArgs& a) {
   return st;
 }
 
+// The per-column constants of a gradient launch (beta.cc:163-168 with sum_theta, beta.cc:30-37, folded in):
+//   ts = theta_k0 + theta_k1 (= theta_sum[k]);  d0n = 1 / theta_k0 - 1 / ts  (y = 0: (1 - y) / Theta0 - 1 / theta_sum),
+//   d1l = 1 / theta_k1 - 1 / ts  (y = 1: y / Theta1 - 1 / theta_sum),  noo = 0 - 1 / ts  (the other component).
+// They depend on theta alone, so they are computed ONCE per theta -- by theta_coef_kernel in front of an eager gradient
+// launch, by the theta step itself inside the descriptor loop -- into a [K] float4 table the gradient kernels load,
+// instead of by every one of a launch's 2 048 waves (three IEEE divisions per column: 14 000 of a wave's 131 500 cycles
+// at K = 1024, in-kernel stamps of round 3).  An IEEE division gives the same quotient wherever it is evaluated, so the
+// table holds exactly what the kernels used to compute for themselves.
+__device__ __forceinline__ void theta_coef(uint32_t k, float t0, float t1, float beta_k, float4* coef, float* theta_sum) {
+  const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
+  theta_sum[k] = ts;
+  const float oo = 1.0f / ts;
+  coef[k] = make_float4(beta_k, 1.0f / t0 - oo, 1.0f / t1 - oo, 0.0f - oo);
+}
+
+__global__ __launch_bounds__(256) void theta_coef_kernel(const float* theta, const float* beta, float4* coef,
+                                                         float* theta_sum, uint32_t K) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) theta_coef(k, theta[2 * k], theta[2 * k + 1], beta[2 * k + 1], coef, theta_sum);
+}
+
 // FUSE: update_pi folded in, as in beta_grads_lds_kernel<KPT, 1, true> below (which has the description): the rows come
 // from phi_vec, are normalised with update_pi_kernel<L, KPT>'s arithmetic as they are consumed, and are stored to pi.
 template <int L, int KPT, bool FUSE = false, bool ONE = false>
@@ -92,15 +124,12 @@ __global__ __launch_bounds__(Group<L>::BLOCK) void beta_grads_kernel(const BetaA
   for (int j = 0; j < KPT; ++j) {
     const uint32_t k = l + j * L;
     if (k < K) {
-      const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
-      const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
-      if (gs == 0) a.theta_sum[k] = ts;
-      const float oo = 1.0f / ts;
-      bk[j] = a.beta[2 * k + 1];
+      const float4 c = a.coef[k];  // (theta_coef above)
+      bk[j] = c.x;
       omb[j] = 1.0f - bk[j];
-      d0n[j] = 1.0f / t0 - oo;  // y = 0: (1 - y) / Theta0 - 1/theta_sum
-      d1l[j] = 1.0f / t1 - oo;  // y = 1:  y / Theta1      - 1/theta_sum
-      noo[j] = 0.0f - oo;       // the other component: 0 / Theta - 1/theta_sum
+      d0n[j] = c.y;  // y = 0: (1 - y) / Theta0 - 1/theta_sum
+      d1l[j] = c.z;  // y = 1:  y / Theta1      - 1/theta_sum
+      noo[j] = c.w;  // the other component: 0 / Theta - 1/theta_sum
     } else {
       bk[j] = omb[j] = d0n[j] = d1l[j] = noo[j] = 0.0f;
     }
@@ -320,28 +349,20 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
   if (gs >= st.P) return;          // block-uniform
   const float EPS = a.epsilon;
   BETA_TRACE(0);
+  BETA_BLK(0);
 
   f32x2 bk[HP], d0n[HP], d1l[HP], noo[HP];
+  auto load_coef = [&]() {  // the lane's per-column constants (theta_coef above): one 16-byte load per column
 #pragma unroll
-  for (int p = 0; p < HP; ++p) {
-    float c[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t k = tid + 2 * L * p + L * h;
-      const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
-      const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
-      if (gs == 0) a.theta_sum[k] = ts;
-      const float oo = 1.0f / ts;
-      c[h][0] = a.beta[2 * k + 1];
-      c[h][1] = 1.0f / t0 - oo;
-      c[h][2] = 1.0f / t1 - oo;
-      c[h][3] = 0.0f - oo;
+    for (int p = 0; p < HP; ++p) {
+      const float4 c0 = a.coef[tid + 2 * L * p], c1 = a.coef[tid + 2 * L * p + L];
+      bk[p] = f32x2{c0.x, c1.x};
+      d0n[p] = f32x2{c0.y, c1.y};
+      d1l[p] = f32x2{c0.z, c1.z};
+      noo[p] = f32x2{c0.w, c1.w};
     }
-    bk[p] = f32x2{c[0][0], c[1][0]};
-    d0n[p] = f32x2{c[0][1], c[1][1]};
-    d1l[p] = f32x2{c[0][2], c[1][2]};
-    noo[p] = f32x2{c[0][3], c[1][3]};
-  }
+  };
+  if constexpr (FUSE || W > 1) load_coef();  // (the plain one-wave form requests its first rows first, below)
   f32x2 acc0[HP], acc1[HP];
 #pragma unroll
   for (int p = 0; p < HP; ++p) acc0[p] = acc1[p] = f32x2{0.0f, 0.0f};
@@ -353,19 +374,65 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 
   // keys and link bits: lane i of every wave holds trip tb + i (and tb + 64 + i in the second window), probed one
   // whole window ahead -- see the register kernel
-  auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
+  auto load_key = [&](uint32_t tb) -> unsigned long long {  // the key of trip tb + ln
     const bool ok = tb + ln < trips;
     const uint64_t e = (uint64_t)st.edge_begin + gs + (uint64_t)(tb + ln) * st.P;
-    const unsigned long long edge = a.edges[ok ? e : st.edge_begin];
+    return a.edges[ok ? e : st.edge_begin];
+  };
+  auto probe_key = [&](unsigned long long edge) -> unsigned long long {  // link bits of a window (one per lane)
     const uint32_t u = (uint32_t)(edge >> 32), v = (uint32_t)(edge & 0xffffffffu);
-    *ymask = __ballot(set_has(a.set, make_edge(u, v)));
+    return __ballot(set_has(a.set, make_edge(u, v)));
+  };
+  auto load_keys = [&](uint32_t tb, unsigned long long* ymask) -> unsigned long long {
+    const unsigned long long edge = load_key(tb);
+    *ymask = probe_key(edge);
     return edge;
   };
   uint32_t tb = 0;
   unsigned long long ym = 0, ym_next = 0;
   BETA_TRACE(1);
-  unsigned long long kv = load_keys(0, &ym), kv_next = 0;
+  unsigned long long kv = load_key(0), kv_next = 0;
+  // The plain one-wave form puts NOTHING between a slot's first keys and its first row requests: the D rows the ring
+  // holds are asked for as soon as the keys are there (the second end points come out of the key window by readlane),
+  // then the per-column constants and the first end point's row, and only then the edge-set probes -- whose round trip
+  // the rows' flight now covers.  (Round 3 had three IEEE divisions per column and both windows' probes in front of the
+  // first request: 20 000 of a wave's 131 500 cycles.)
+  f32x2 pa[HP];
+  uint32_t cur_u = 0xffffffffu;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) pa[p] = f32x2{0.0f, 0.0f};
+  uint32_t issued = 0;  // (plain one-wave form) rows requested so far
+  if constexpr (!FUSE && W == 1) {
+#pragma unroll
+    for (uint32_t k = 0; k < D; ++k) {
+      if (k < trips) {
+        const uint32_t v = (uint32_t)(wave_lane_u64(kv, k) & 0xffffffffu);
+        const float* rb = rpm_row(a.pi, v) + 4 * tid;
+        char* dst = wave_smem + k * (KW * sizeof(float));
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+          __builtin_amdgcn_global_load_lds((beta_glb_void_t*)(rb + 4 * L * p), (beta_lds_void_t*)(dst + 1024 * p), 16, 0, 0);
+        ++issued;
+      }
+    }
+    load_coef();
+    if (trips > 0) {  // the first end point of the slot's first edge (shared by every edge of a node-strategy mini-batch)
+      cur_u = (uint32_t)(wave_lane_u64(kv, 0) >> 32);
+      const float* ra = rpm_row(a.pi, cur_u);
+#pragma unroll
+      for (int p = 0; p < HP; ++p) pa[p] = f32x2{ra[tid + 2 * L * p], ra[tid + 2 * L * p + L]};
+    }
+  }
+  ym = probe_key(kv);
   if (trips > 64u) kv_next = load_keys(64, &ym_next);  // (block-uniform; a slot of at most 64 edges never looks there)
+  if constexpr (!FUSE && W == 1) {
+    // everything the prologue loaded is waited for HERE, not at the loop's first use (a load left pending across the
+    // loop's back edge makes hipcc's wait-count pass drain the row ring on every trip, see below)
+#pragma unroll
+    for (int p = 0; p < HP; ++p)
+      asm volatile("" : "+v"(pa[p].x), "+v"(pa[p].y), "+v"(bk[p].x), "+v"(bk[p].y), "+v"(d0n[p].x), "+v"(d0n[p].y), "+v"(d1l[p].x),
+                   "+v"(d1l[p].y), "+v"(noo[p].x), "+v"(noo[p].y));
+  }
   BETA_TRACE(2);
 
   auto key_of = [&](uint32_t t, bool* y) -> unsigned long long {
@@ -421,10 +488,6 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     }
   };
 
-  f32x2 pa[HP];
-  uint32_t cur_u = 0xffffffffu;
-#pragma unroll
-  for (int p = 0; p < HP; ++p) pa[p] = f32x2{0.0f, 0.0f};
   uint32_t shared_node = 0;
   if constexpr (FUSE) {  // the shared end point: node 0, normalised here by every slot, stored by slot 0
     shared_node = a.fuse.nodes[0];
@@ -456,7 +519,6 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     // their four sums advance as one transposed four-row chain / tree (VLane::chain_rows<4> / tree_rows<4>), and the
     // accumulators take edge t before edge t + 1: bit-identical to the one-edge loop.  The ring (D = 4 rows) is kept
     // full: rows t .. t + 3 are in it or on their way whenever rows < t have been consumed.
-    uint32_t issued = 0;
     auto fill = [&](uint32_t t) {
 #pragma unroll
       for (uint32_t k = 0; k < D; ++k) {
@@ -737,6 +799,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     *reinterpret_cast<float2*>(out + 2 * (tid + 2 * L * p)) = make_float2(acc0[p].x, acc1[p].x);
     *reinterpret_cast<float2*>(out + 2 * (tid + 2 * L * p + L)) = make_float2(acc0[p].y, acc1[p].y);
   }
+  BETA_BLK(1);
 }
 
 template <int KPT, int W, int VL = 64>
@@ -816,9 +879,11 @@ __global__ __launch_bounds__(256) void sum_partials8_kernel(const float* partial
 
 // update_theta (beta.cc:51-82) + beta = pair-normalised theta (beta.cc:376-383; Normalizer slice 2,
 // wg 1: lsum = (0 + t0) + t1) for component k: stream k draws r0 for theta[k,0], then r1 for theta[k,1].
+// coef / theta_sum (descriptor loop; null on the eager path): the stepped theta's gradient constants for the NEXT
+// iteration's gradient kernel (theta_coef above) -- nobody else changes theta between this step and that launch.
 __device__ __forceinline__ void theta_step(uint32_t k, float g0, float g1, float* theta, float* beta, ammsb_seed* seeds,
                                            float eps_t, float scale, float eta0, float eta1, uint32_t noise_on,
-                                           const ZigTables* zig) {
+                                           const ZigTables* zig, float4* coef = nullptr, float* theta_sum = nullptr) {
   ammsb_seed rs = seeds[k];
   const float half = eps_t / 2.0f;
   float th[2];
@@ -846,7 +911,9 @@ __device__ __forceinline__ void theta_step(uint32_t k, float g0, float g1, float
   lsum += th[0];
   lsum += th[1];
   beta[2 * k] = th[0] / lsum;
-  beta[2 * k + 1] = th[1] / lsum;
+  const float b1 = th[1] / lsum;
+  beta[2 * k + 1] = b1;
+  if (coef) theta_coef(k, th[0], th[1], b1, coef, theta_sum);
 }
 
 // captured graph: hand the next two descriptors of the ring to the graph that runs next, advance the cursor
@@ -893,7 +960,8 @@ __device__ __forceinline__ void step_advance(const ammsb_step_advance& adv, cons
 __global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* beta, const float* grads,
                                                            ammsb_seed* seeds, uint32_t K, float eps_t, float scale,
                                                            float eta0, float eta1, uint32_t noise_on,
-                                                           const ammsb_step_desc* desc, const ammsb_step_advance adv) {
+                                                           const ammsb_step_desc* desc, const ammsb_step_advance adv,
+                                                           float4* coef, float* theta_sum) {
   __shared__ ZigTables zig;
   zig_load(&zig);
   __syncthreads();
@@ -909,7 +977,7 @@ __global__ __launch_bounds__(64) void update_theta_kernel(float* theta, float* b
     if (k == 0) step_advance(adv, desc);
   }
   if (k >= K) return;
-  theta_step(k, grads[2 * k], grads[2 * k + 1], theta, beta, seeds, eps_t, scale, eta0, eta1, noise_on, &zig);
+  theta_step(k, grads[2 * k], grads[2 * k + 1], theta, beta, seeds, eps_t, scale, eta0, eta1, noise_on, &zig, coef, theta_sum);
 }
 
 // sum_grads + update_theta in one launch (captured graph): block b reduces columns 8b .. 8b+7 of the partial rows
@@ -919,7 +987,8 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
                                                                 float* grads_out, float* theta, float* beta,
                                                                 ammsb_seed* seeds, float eta0, float eta1,
                                                                 uint32_t noise_on, const ammsb_step_desc* desc,
-                                                                const ammsb_step_advance adv) {
+                                                                const ammsb_step_advance adv, float4* coef,
+                                                                float* theta_sum) {
   __shared__ float4 red[128][2];
   __shared__ ZigTables zig;
   if (ammsb_desc_skip(desc)) {  // (uniform) a skipped step: gradient, theta, beta and the streams stay as they are
@@ -975,7 +1044,7 @@ __global__ __launch_bounds__(256) void sum_update_theta_kernel(const float* part
     const uint32_t k = blockIdx.x * 4 + threadIdx.x;  // columns 2k, 2k+1 = words (t & 1) * 2, +1 of red[0][t >> 1]
     const float4 g = red[0][threadIdx.x >> 1];
     const float g0 = (threadIdx.x & 1) ? g.z : g.x, g1 = (threadIdx.x & 1) ? g.w : g.y;
-    theta_step(k, g0, g1, theta, beta, seeds, desc->eps_t, desc->scale, eta0, eta1, noise_on, &zig);
+    theta_step(k, g0, g1, theta, beta, seeds, desc->eps_t, desc->scale, eta0, eta1, noise_on, &zig, coef, theta_sum);
   }
 }
 
@@ -1025,14 +1094,11 @@ __global__ __launch_bounds__(512) void beta_grads_gen_kernel(const BetaArgs a, u
   for (int j = 0; j < CPT; ++j) {
     const uint32_t k = col(j);
     if (k < K) {
-      const float t0 = a.theta[2 * k], t1 = a.theta[2 * k + 1];
-      const float ts = t0 + t1;  // sum_theta, beta.cc:30-37
-      if (gs == 0) a.theta_sum[k] = ts;
-      const float oo = 1.0f / ts;
-      bk[j] = a.beta[2 * k + 1];
-      d0n[j] = 1.0f / t0 - oo;
-      d1l[j] = 1.0f / t1 - oo;
-      noo[j] = 0.0f - oo;
+      const float4 c = a.coef[k];  // (theta_coef above)
+      bk[j] = c.x;
+      d0n[j] = c.y;
+      d1l[j] = c.z;
+      noo[j] = c.w;
     } else {
       bk[j] = d0n[j] = d1l[j] = noo[j] = 0.0f;
     }
@@ -1237,7 +1303,8 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
                              const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
                              uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out,
                              const ammsb_step_desc* desc, bool sum_rows, uint32_t* slots_out, void* stream,
-                             const ammsb_pi_fusion* fuse = nullptr, unsigned long long* stamps = nullptr) {
+                             const ammsb_pi_fusion* fuse = nullptr, unsigned long long* stamps = nullptr,
+                             bool coef_ready = false) {
   AMMSB_CHECK_ARG(ctx, ctx && theta && beta && pi && training_set && edges && grads_out, "null argument");
   AMMSB_CHECK_ARG(ctx, pi->num_blocks >= 1 && pi->num_blocks <= AMMSB_RPM_MAX_BLOCKS && pi->rows_in_block > 0,
                   "bad pi descriptor");
@@ -1271,7 +1338,13 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.set = dev_set(*training_set);
   a.edges = edges;
   a.partials = ctx->grad_partials;
-  a.theta_sum = ctx->theta_sum;
+  a.coef = ctx->theta_coef;
+  // the per-column constants of this theta (theta_coef): computed here, unless the caller -- the descriptor loop, whose
+  // theta step writes them and whose run start calls ammsb_theta_coef_d -- vouches for the table
+  if (!coef_ready) {
+    theta_coef_kernel<<<(K + 255) / 256, 256, 0, s>>>(theta, beta, ctx->theta_coef, ctx->theta_sum, K);
+    AMMSB_LAUNCH_CHECK(ctx);
+  }
   a.edge_begin = edge_begin;
   a.edge_end = edge_end;
   a.K = K;
@@ -1354,6 +1427,16 @@ int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, co
                            true, nullptr, stream);
 }
 
+// Run start of the descriptor loop: the gradient constants of the theta the run begins with (every later step's come
+// from the theta step in front of it).
+int ammsb_theta_coef_d(ammsb_ctx* ctx, const float* theta, const float* beta, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && theta && beta, "null argument");
+  const uint32_t K = (uint32_t)ctx->params.K;
+  theta_coef_kernel<<<(K + 255) / 256, 256, 0, as_stream(stream)>>>(theta, beta, ctx->theta_coef, ctx->theta_sum, K);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 // The gradient and the theta/beta step of one captured iteration: partial rows, then ONE kernel that sums them into
 // grads_out and steps theta (falls back to the separate sum and step kernels for shapes the fused one does not take).
 int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,
@@ -1366,12 +1449,13 @@ int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm
   const bool fused = (2 * K) % 8 == 0 && (reinterpret_cast<uintptr_t>(grads_out) & 15) == 0;
   uint32_t slots = 0;
   int rc = beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges_cap, 0, n_edges_cap, wg, grads_out, desc,
-                             !fused, &slots, stream, fuse, stamps);
+                             !fused, &slots, stream, fuse, stamps, /*coef_ready=*/true);
   if (rc != AMMSB_OK) return rc;
   if (!fused) return ammsb_update_theta_d(ctx, theta, beta, grads_out, seeds, flags, desc, adv, stream);
   sum_update_theta_kernel<<<2 * K / 8, 256, 0, as_stream(stream)>>>(ctx->grad_partials, slots, 2 * K, grads_out, theta, beta,
                                                                       seeds, p.eta0, p.eta1,
-                                                                      (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc, *adv);
+                                                                      (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc, *adv,
+                                                                      ctx->theta_coef, ctx->theta_sum);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1410,7 +1494,7 @@ extern "C" int ammsb_update_theta(ammsb_ctx* ctx, float* theta, float* beta, con
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K,
                                                                      ammsb_eps_t(&p, step_count), scale, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u,
-                                                                     nullptr, none);
+                                                                     nullptr, none, nullptr, nullptr);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }
@@ -1423,7 +1507,7 @@ int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float*
   const ammsb_step_advance none = {nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, 0ull, nullptr};
   update_theta_kernel<<<(K + 63) / 64, 64, 0, as_stream(stream)>>>(theta, beta, grads, seeds, K, 0.0f, 0.0f, p.eta0,
                                                                      p.eta1, (flags & AMMSB_NOISE_OFF) ? 0u : 1u, desc,
-                                                                     adv ? *adv : none);
+                                                                     adv ? *adv : none, ctx->theta_coef, ctx->theta_sum);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

@@ -78,8 +78,11 @@ extern "C" int ammsb_ctx_create(int device_id, const ammsb_params* params, ammsb
   const size_t K = params->K;
   if (hipMalloc(&ctx->grad_partials, sizeof(float) * ctx->max_partials * 2 * K) != hipSuccess ||
       hipMalloc(&ctx->theta_sum, sizeof(float) * K) != hipSuccess ||
+      hipMalloc(&ctx->theta_coef, sizeof(float4) * K) != hipSuccess ||
       hipMalloc(&ctx->ppx_partials, sizeof(double) * ctx->max_ppx_blocks * 2) != hipSuccess ||
-      hipMalloc(&ctx->ppx_cnt_partials, sizeof(unsigned long long) * ctx->max_ppx_blocks * 2) != hipSuccess) {
+      hipMalloc(&ctx->ppx_cnt_partials, sizeof(unsigned long long) * ctx->max_ppx_blocks * 2) != hipSuccess ||
+      hipMalloc(&ctx->ppx_ticket, sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(ctx->ppx_ticket, 0, sizeof(uint32_t)) != hipSuccess) {
     ammsb_ctx_destroy(ctx);
     return AMMSB_ENOMEM;
   }
@@ -92,8 +95,10 @@ extern "C" int ammsb_ctx_destroy(ammsb_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->grad_partials) (void)hipFree(ctx->grad_partials);
   if (ctx->theta_sum) (void)hipFree(ctx->theta_sum);
+  if (ctx->theta_coef) (void)hipFree(ctx->theta_coef);
   if (ctx->ppx_partials) (void)hipFree(ctx->ppx_partials);
   if (ctx->ppx_cnt_partials) (void)hipFree(ctx->ppx_cnt_partials);
+  if (ctx->ppx_ticket) (void)hipFree(ctx->ppx_ticket);
   free(ctx);
   return AMMSB_OK;
 }
@@ -696,6 +701,33 @@ extern "C" int ammsb_rpm_fetch(ammsb_ctx* ctx, const ammsb_rpm* m, uint64_t row,
   if (rc) return rc;
   AMMSB_CHECK_ARG(ctx, row < m->num_rows && col + 1 < m->num_cols, "row/col out of range");
   rpm_fetch_kernel<<<1, 1, 0, as_stream(stream)>>>(*m, row, col, out);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
+// ---- measurement aid: the shader clock each XCD holds while whatever else is running runs (DVFS give-back) ----
+// One wave per block spins on the 100 MHz wall clock for `ticks` ticks and notes shader cycles / wall ticks / XCC_ID
+// of its own lifetime; blocks are dealt round-robin over the XCDs, so 64 of them cover all eight.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  unsigned long long w1 = w0;
+  while (w1 - w0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    w1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  w1 = __builtin_amdgcn_s_memrealtime();
+  out[3 * blockIdx.x + 0] = c1 - c0;
+  out[3 * blockIdx.x + 1] = w1 - w0;
+  out[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;  // HW_REG_XCC_ID
+}
+
+extern "C" int ammsb_clock_probe(ammsb_ctx* ctx, uint64_t* out, uint32_t n_blocks, uint32_t spin_us, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && out, "null argument");
+  AMMSB_CHECK_ARG(ctx, n_blocks >= 1 && n_blocks <= 4096 && spin_us >= 1 && spin_us <= 100000, "blocks in [1, 4096], spin in [1, 100000] us");
+  clock_probe_kernel<<<n_blocks, 64, 0, as_stream(stream)>>>(reinterpret_cast<unsigned long long*>(out), 100ull * spin_us);
   AMMSB_LAUNCH_CHECK(ctx);
   return AMMSB_OK;
 }

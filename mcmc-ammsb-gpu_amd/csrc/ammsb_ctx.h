@@ -18,9 +18,11 @@ struct ammsb_ctx {
   float* grad_partials;      // [max_partials, 2K]
   uint32_t max_partials;
   float* theta_sum;          // [K]   (BetaUpdater::GetThetaSum())
+  float4* theta_coef;        // [K]   per-column constants of the gradient kernels (theta_coef, ammsb_beta.hip)
   double* ppx_partials;      // [max_ppx_blocks, 2]
   unsigned long long* ppx_cnt_partials;  // [max_ppx_blocks, 2]
   uint32_t max_ppx_blocks;
+  uint32_t* ppx_ticket;      // [1]   blocks of a self-reducing perplexity launch that have written their partials (0 between launches)
   // name of the kernel the last update_phi / update_pi / beta gradient / perplexity call dispatched to, as the
   // rocprofv3 kernel trace spells it (ammsb_last_kernel_name)
   const char* kernel_name[5];

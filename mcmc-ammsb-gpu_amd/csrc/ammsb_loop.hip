@@ -588,6 +588,9 @@ int submit(ammsb_loop* lp, const ammsb_mb_choice* pending, const ammsb_mb_choice
     loop_prime_kernel<<<1, 1, 0, lp->main>>>(lp->d_ring, lp->d_cursor, lp->d_cur[dp0], lp->d_nxt[(p0 + done + 2) % NBUF],
                                              ev ? nullptr : lp->d_hs + HS_TIMEOUTS);
     LOOP_HIP(lp, hipGetLastError());
+    // the gradient constants of the theta this chunk starts from (ammsb_beta_step_d's theta step keeps them current
+    // from here on; theta may have been stepped eagerly or restored from a checkpoint since the last run)
+    LOOP_RC(ammsb_theta_coef_d(ctx, lp->c.theta, lp->c.beta, lp->main));
     LOOP_HIP(lp, hipEventRecord(lp->ev_prime, lp->main));
     if (done == done0) {
       // ramp-up: the mini-batches of steps done0 and done0 + 1 that are not there yet are sampled before the first

@@ -33,16 +33,17 @@ __device__ unsigned long long g_phi_trace[256];
 extern "C" int ammsb_debug_trace(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phi_trace), sizeof(unsigned long long) * (n < 256 ? n : 256)) == hipSuccess ? 0 : -2;
 }
+#define AMMSB_PHI_BLK_CAP 65536
 // per-block occupancy record: [block][0..3] = shader clock at start / end, 100 MHz wall clock at start / end,
 // [4] = HW_ID | XCC_ID << 32 (which CU / SIMD / wave slot the block ran on)
-__device__ unsigned long long g_phi_blk[16384 * 5];
-#define PHI_BLK(end) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { \
+__device__ unsigned long long g_phi_blk[AMMSB_PHI_BLK_CAP * 5];
+#define PHI_BLK(end) do { if (threadIdx.x == 0 && blockIdx.x < AMMSB_PHI_BLK_CAP) { \
     g_phi_blk[blockIdx.x * 5 + (end)] = __builtin_readcyclecounter(); \
     g_phi_blk[blockIdx.x * 5 + 2 + (end)] = __builtin_amdgcn_s_memrealtime(); \
     if (!(end)) g_phi_blk[blockIdx.x * 5 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
                                                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } while (0)
 extern "C" int ammsb_debug_blocks(unsigned long long* out, int n_blocks) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phi_blk), sizeof(unsigned long long) * 5 * (n_blocks < 16384 ? n_blocks : 16384)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phi_blk), sizeof(unsigned long long) * 5 * (n_blocks < AMMSB_PHI_BLK_CAP ? n_blocks : AMMSB_PHI_BLK_CAP)) == hipSuccess ? 0 : -2;
 }
 #else
 #define PHI_TRACE(slot) do { } while (0)
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
   }
   const uint32_t g = a.group_begin + blockIdx.x * NB + nb;
   if (g >= st.group_end) return;  // uniform per node group
+  PHI_BLK(0);
   const float EPS = a.epsilon;
   if constexpr (NB == 1) {
     if (a.noise_on) zig_load(&zig);
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
     }
   }
   if (a.noise_on && tid < LV) a.seeds[(uint64_t)g * LV + tid] = rs;
+  PHI_BLK(1);
 }
 
 // ---------------------------------------------------------------------------------------------------------

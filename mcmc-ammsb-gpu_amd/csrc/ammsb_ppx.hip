@@ -28,7 +28,63 @@ struct PpxArgs {
   unsigned long long* cnt_partials;  // [P, 2]
   uint32_t edge_begin, edge_end, P, K, call_count;
   float epsilon;
+  // (ppx_lds_kernel) the launch reduces its own partials: every block draws a ticket when its partials are out, the
+  // block that draws the last one adds them up in ppx_reduce_kernel's order and writes *out -- no second launch
+  uint32_t* ticket;     // zero before the launch; the reducing block resets it
+  ammsb_ppx_sums* out;  // device memory or host-mapped pinned memory
 };
+
+// The four reductions of perplexity.cc:318-331 over the P per-slot partials, in ONE fixed order whoever runs it:
+// virtual thread t of 256 adds slots t, t + 256, ... ascending, then the halving tree over the 256.  Here one wave runs
+// it (lane l carries virtual threads l, l + 64, l + 128, l + 192: the tree's levels 128 and 64 are in-lane adds, the
+// levels 32 .. 1 go through `scratch`, >= 2 KiB of LDS the caller no longer needs) -- ppx_reduce_kernel below runs the
+// same order with 256 real threads, so the folded and the two-launch forms agree bit for bit.
+__device__ __forceinline__ void ppx_reduce_wave(const double* ll, const unsigned long long* cnt, uint32_t P, void* scratch,
+                                                ammsb_ppx_sums* out) {
+  const uint32_t l = threadIdx.x & 63u;
+  double a0[4], a1[4];
+  unsigned long long c0[4], c1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a0[j] = a1[j] = 0.0;
+    c0[j] = c1[j] = 0ull;
+    for (uint32_t p = l + 64u * j; p < P; p += 256u) {
+      a0[j] += ll[2 * p];
+      a1[j] += ll[2 * p + 1];
+      c0[j] += cnt[2 * p];
+      c1[j] += cnt[2 * p + 1];
+    }
+  }
+  // level 128: s[t] += s[t + 128] (t < 128); level 64: s[t] += s[t + 64] (t < 64)
+  a0[0] += a0[2]; a0[1] += a0[3]; a0[0] += a0[1];
+  a1[0] += a1[2]; a1[1] += a1[3]; a1[0] += a1[1];
+  c0[0] += c0[2]; c0[1] += c0[3]; c0[0] += c0[1];
+  c1[0] += c1[2]; c1[1] += c1[3]; c1[0] += c1[1];
+  double* s_ll = reinterpret_cast<double*>(scratch);                                   // [2][64]
+  unsigned long long* s_c = reinterpret_cast<unsigned long long*>(s_ll + 128);         // [2][64]
+  s_ll[l] = a0[0];
+  s_ll[64 + l] = a1[0];
+  s_c[l] = c0[0];
+  s_c[64 + l] = c1[0];
+  for (uint32_t p2 = 32; p2 > 0; p2 >>= 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order)
+    __builtin_amdgcn_wave_barrier();
+    if (l < p2) {
+      s_ll[l] += s_ll[l + p2];
+      s_ll[64 + l] += s_ll[64 + l + p2];
+      s_c[l] += s_c[l + p2];
+      s_c[64 + l] += s_c[64 + l + p2];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (l == 0) {
+    out->link_ll = s_ll[0];
+    out->nonlink_ll = s_ll[64];
+    out->link_cnt = s_c[0];
+    out->nonlink_cnt = s_c[64];
+  }
+}
 
 template <int L, int KPT>
 __global__ __launch_bounds__(Group<L>::BLOCK) void ppx_kernel(const PpxArgs a) {
@@ -271,6 +327,25 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
     a.cnt_partials[2 * gs] = c_link;
     a.cnt_partials[2 * gs + 1] = c_non;
   }
+  if (!a.ticket) return;  // (launch-uniform) the two-launch form: ppx_reduce_kernel follows
+  // The launch adds up its own partials (cdna_hip_programming.md, split-K in-launch reduction / Guideline 16): partial
+  // stores drained -> agent-scope release -> ticket; the block that draws the last ticket makes one agent-scope acquire
+  // and reads every slot's partials with plain loads.  One wave per block: no barrier, the "I am last" word travels
+  // by readfirstlane (no second __shared__ object beside the ring).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t last = 0;
+  if (l == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (kept: ROCm 7.2 can drop the fence's own wait)
+    last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.P - 1u ? 1u : 0u;
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring's last reads are done: its first 2 KiB are the scratch
+  ppx_reduce_wave(a.ll_partials, a.cnt_partials, a.P, smem, a.out);
+  if (l == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -404,9 +479,13 @@ int launch_ppx_lds(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * sizeof(float) * 64 * KPT;
   static const std::string name = ammsb_kname("ppx_lds_kernel<%d, 2u, %d>", KPT, VL);
   ctx->kernel_name[AMMSB_KN_PPX] = name.c_str();
-  ppx_lds_kernel<KPT, 2, VL><<<a.P, 64, lds, s>>>(a);
+  PpxArgs f = a;
+  f.ticket = ctx->ppx_ticket;  // this form reduces its own partials (no ppx_reduce_kernel launch)
+  static const bool two_launch = getenv("AMMSB_PPX_FOLD") && atoi(getenv("AMMSB_PPX_FOLD")) == 0;  // (A/B, tests)
+  if (two_launch) f.ticket = nullptr;
+  ppx_lds_kernel<KPT, 2, VL><<<a.P, 64, lds, s>>>(f);
   AMMSB_LAUNCH_CHECK(ctx);
-  return AMMSB_OK;
+  return f.ticket ? 1 : AMMSB_OK;  // 1 = done, sums written
 }
 
 // fixed-order reduction of the P per-slot partials: thread t adds slots t, t+256, ... ascending,
@@ -532,6 +611,8 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
   a.K = K;
   a.call_count = call_count;
   a.epsilon = ctx->params.epsilon;
+  a.ticket = nullptr;
+  a.out = out;
   const uint32_t span = edge_end - edge_begin;
   uint32_t want = (uint32_t)ctx->num_cus * 8u * 64u / (wg < 64 ? 64u : wg) * (wg < 64 ? 64u / wg : 1u);
   // (the one-wave-per-slot LDS form at wg 32 wants the slot count of the wg 64 form: 8 resident waves per CU)
@@ -549,6 +630,7 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
     if (K == 256) rc = launch_ppx_lds<4, 32>(ctx, a, s);
     else if (K == 512) rc = launch_ppx_lds<8, 32>(ctx, a, s);
     else rc = launch_ppx_lds<16, 32>(ctx, a, s);
+    if (rc == 1) return AMMSB_OK;  // (the launch reduced its own partials)
     if (rc) return rc;
   } else if (generic) {
     const int rc = launch_ppx_gen(ctx, a, wg, s);
@@ -560,6 +642,7 @@ extern "C" int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_r
       case 8: rc = launch_ppx_lds<8>(ctx, a, s); break;
       default: rc = launch_ppx_lds<16>(ctx, a, s); break;
     }
+    if (rc == 1) return AMMSB_OK;  // (the launch reduced its own partials)
     if (rc) return rc;
   } else {
     AMMSB_DISPATCH_HOT_L(wg, AMMSB_DISPATCH_KPT(kpt, {

@@ -97,6 +97,9 @@ int ammsb_update_pi_d(ammsb_ctx* ctx, const ammsb_rpm* pi, float* phi_sum, const
 int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
                        const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges_cap, uint32_t wg,
                        float* grads_out, const ammsb_step_desc* desc, void* stream);
+// (ammsb_beta_step_d trusts the context's table of per-column gradient constants: its own theta step keeps it current,
+// and whoever starts a sequence of such steps calls this first)
+int ammsb_theta_coef_d(ammsb_ctx* ctx, const float* theta, const float* beta, void* stream);
 int ammsb_update_theta_d(ammsb_ctx* ctx, float* theta, float* beta, const float* grads, ammsb_seed* seeds,
                          uint32_t flags, const ammsb_step_desc* desc, const ammsb_step_advance* adv, void* stream);
 int ammsb_beta_step_d(ammsb_ctx* ctx, float* theta, float* beta, const ammsb_rpm* pi, const ammsb_set* training_set,

@@ -10,6 +10,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -35,14 +36,18 @@ struct Option {
 template <class T>
 Option Opt(const std::string& name, char s, T* target, const std::string& def) {
   return Option{name, s, def, [target](const std::string& v) {
-                  std::istringstream in(v);
-                  in >> std::boolalpha >> *target;
-                  if (in.fail()) {  // bool also accepts 0/1, as program_options does
-                    std::istringstream again(v);
-                    again >> *target;
-                    return !again.fail();
+                  try {  // (the enum / pair parsers throw on a bad token: config.cc:118-131)
+                    std::istringstream in(v);
+                    in >> std::boolalpha >> *target;
+                    if (in.fail()) {  // bool also accepts 0/1, as program_options does
+                      std::istringstream again(v);
+                      again >> *target;
+                      return !again.fail();
+                    }
+                    return true;
+                  } catch (const std::exception&) {
+                    return false;
                   }
-                  return true;
                 }};
 }
 
@@ -213,7 +218,13 @@ int main(int argc, char** argv) {
             << ", heldout max fan out = " << cfg.heldoutGraph->MaxFanOut() << ")" << std::endl;
   std::cerr << "I " << cfg << std::endl;
   signal(SIGINT, handler);
-  mcmc::Learner learner(cfg, queue);
+  std::unique_ptr<mcmc::Learner> learner_ptr;
+  try {
+    learner_ptr.reset(new mcmc::Learner(cfg, queue));
+  } catch (const std::exception& e) {  // the reference LOG(FATAL)s on an unusable configuration (phi.cc:660, learner.cc:146)
+    Fatal(e.what());
+  }
+  mcmc::Learner& learner = *learner_ptr;
   if (!ckptIn.empty()) {
     std::ifstream in(ckptIn, std::ios::binary);
     if (!in.good() || !learner.Parse(&in)) Fatal("cannot restore checkpoint " + ckptIn);

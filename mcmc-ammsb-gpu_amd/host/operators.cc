@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <iostream>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -272,10 +273,42 @@ void DeferredTimer::Resolve(bool all) {
   pending_.erase(pending_.begin(), pending_.begin() + static_cast<std::ptrdiff_t>(n));
 }
 
+// What the reference's kernel-variant switches mean here (phi.cc:608-700, main.cc:71-76).  The three work-group modes
+// run the same arithmetic on the same lane <-> column <-> stream map (phi.cc:214-275 / :318-368 / :420-606 differ only
+// in where pi_a / probs / grads live), so they all map onto the one HIP kernel family.  Two settings change RESULTS in
+// the reference and are not reproduced: PHI_NODE_PER_THREAD draws a node's noise from ONE stream per node
+// (phi.cc:124-152, rand_ sized max_nodes * 1) -- refused; phi_vector_width > 1 hands lane l the column vectors
+// l, l + wg, ... of K / width (Floatn ownership, v_accn partial sums, `width` draws per vector: phi.cc:214-275) --
+// computed as width 1, with a warning.  sum_grads_vector_width only widens the loads of sum_grads (beta.cc:39-49:
+// the same per-column additions in the same order), which has no numerical effect to reproduce.
+static const Config& CheckedPhiConfig(const Config& cfg) {
+  if (cfg.phi_mode == PHI_NODE_PER_THREAD)
+    throw std::invalid_argument(
+        "phi_mode PHI_NODE_PER_THREAD is the reference's CPU-device kernel (one RNG stream per node, phi.cc:124-152): "
+        "no MI355X form; use a PHI_NODE_PER_WORKGROUP_* mode");
+  if (cfg.phi_mode != PHI_NODE_PER_WORKGROUP_NAIVE)
+    std::cerr << "W phi_mode " << to_string(cfg.phi_mode) << ": runs the PHI_NODE_PER_WORKGROUP_NAIVE kernel family "
+              << "(same arithmetic, lane-to-column map and RNG streams; the modes differ only in operand placement)"
+              << std::endl;
+  if (cfg.phi_probs_shared != true || cfg.phi_grads_shared != true || cfg.phi_pi_shared != true)
+    std::cerr << "W phi-probs-shared / phi-grads-shared / phi-pi-shared: operand placement is the library's choice "
+              << "(registers / LDS ring); results do not depend on it" << std::endl;
+  if (cfg.phi_vector_width != 1)
+    std::cerr << "W phi_vector_width " << cfg.phi_vector_width << ": NOT reproduced -- results follow phi_vector_width 1 "
+              << "(lane l owns columns l, l + wg, ...; one draw per column in ascending order).  The reference's width-"
+              << cfg.phi_vector_width << " kernels give lane l the column vectors l, l + wg, ... of K / width and sum "
+              << "a vector's components before the lane partial (phi.cc:214-275), which changes WG_SUM's association "
+              << "and the stream-to-column map" << std::endl;
+  if (cfg.sum_grads_vector_width != 1)
+    std::cerr << "W sum_grads_vector_width " << cfg.sum_grads_vector_width << ": accepted; sum_grads' vector width only "
+              << "widens its loads (beta.cc:39-49), the sums are the same" << std::endl;
+  return cfg;
+}
+
 PhiUpdater::PhiUpdater(const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
                        RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Float>& phi, OpenClSet* trainingSet,
                        const std::vector<std::string>&, const std::string&)
-    : ctx_(AcquireContext(cfg, queue)),
+    : ctx_(AcquireContext(CheckedPhiConfig(cfg), queue)),
       queue_(queue),
       beta_(beta),
       pi_(pi),
@@ -370,10 +403,19 @@ bool PhiUpdater::Parse(std::istream* in) {
 
 // ----------------------------------------------------------------------------- BetaUpdater
 
-BetaUpdater::BetaUpdater(Mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& theta,
+// EDGE_PER_THREAD is what the reference picks on a CPU device (learner.cc:105-114): the same terms added in another
+// order (beta.cc:87-136, perplexity.cc:16-84).  There is one (work-group) kernel family here; say so instead of
+// silently returning work-group-ordered sums to a caller who asked for the other mode.
+static void WarnPerThreadMode(const char* who, bool per_thread) {
+  if (per_thread)
+    std::cerr << "W " << who << ": EDGE_PER_THREAD requested; the MI355X build runs the EDGE_PER_WORKGROUP form (same "
+              << "terms, work-group summation order)" << std::endl;
+}
+
+BetaUpdater::BetaUpdater(Mode mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& theta,
                          clcuda::Buffer<Float>& beta, RowPartitionedMatrix<Float>* pi, OpenClSet* trainingSet,
                          const std::vector<std::string>&, const std::string&)
-    : ctx_(AcquireContext(cfg, queue)),
+    : ctx_((WarnPerThreadMode("BetaUpdater", mode == EDGE_PER_THREAD), AcquireContext(cfg, queue))),
       queue_(queue),
       theta_(theta),
       beta_(beta),
@@ -473,10 +515,10 @@ bool BetaUpdater::Parse(std::istream* in) {
 
 // -------------------------------------------------------------------- PerplexityCalculator
 
-PerplexityCalculator::PerplexityCalculator(Mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
+PerplexityCalculator::PerplexityCalculator(Mode mode, const Config& cfg, clcuda::Queue queue, clcuda::Buffer<Float>& beta,
                                            RowPartitionedMatrix<Float>* pi, clcuda::Buffer<Edge>& edges,
                                            OpenClSet* edgeSet, const std::vector<std::string>&, const std::string&)
-    : ctx_(AcquireContext(cfg, queue)),
+    : ctx_((WarnPerThreadMode("PerplexityCalculator", mode == EDGE_PER_THREAD), AcquireContext(cfg, queue))),
       queue_(queue),
       beta_(beta),
       pi_(pi),
@@ -486,6 +528,12 @@ PerplexityCalculator::PerplexityCalculator(Mode, const Config& cfg, clcuda::Queu
       sums_(queue.GetContext(), 1),
       count_calls_(0),
       local_(cfg.ppx_wg_size) {
+  // operator()() has its 32-byte result written straight into pinned host memory (one launch + one Finish, no copy)
+  ammsb_ppx_sums* hs = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&hs), sizeof(ammsb_ppx_sums), hipHostMallocDefault) != hipSuccess || !hs)
+    throw std::runtime_error("PerplexityCalculator: hipHostMalloc failed");
+  std::memset(hs, 0, sizeof *hs);
+  host_sums_.reset(hs, [](ammsb_ppx_sums* p) { (void)hipHostFree(p); });
   std::vector<Float> zero(edges.Count(), 0);  // perplexity.cc:204-205
   ppx_per_edge_.Write(queue_, zero.size(), zero.data());
 }
@@ -496,11 +544,10 @@ Float PerplexityCalculator::operator()() {
   EventTimer t(queue_.stream());
   ThrowIfError(ctx_.get(),
                ammsb_perplexity(ctx_.get(), beta_.data(), &pi_->Get(), &edgeSet_->Get(), edges_.data(), H, 0, H,
-                                count_calls_, local_, ppx_per_edge_.data(), sums_.data(), queue_.stream()),
+                                count_calls_, local_, ppx_per_edge_.data(), host_sums_.get(), queue_.stream()),
                "ammsb_perplexity");
-  t_ppx_ += t.StopNs();
-  ammsb_ppx_sums s;
-  sums_.Read(queue_, 1, &s);
+  t_ppx_ += t.StopNs();  // (waits for the launch: the sums are in host memory)
+  const ammsb_ppx_sums s = *host_sums_;
   double avg = 0.0;  // perplexity.cc:264-268
   if (s.link_cnt + s.nonlink_cnt != 0) avg = (s.link_ll + s.nonlink_ll) / static_cast<double>(s.link_cnt + s.nonlink_cnt);
   return static_cast<Float>(-avg);

@@ -96,6 +96,32 @@ class Config:
         return cls(**base)
 
 
+def _check_kernel_variant_knobs(cfg):
+    """The reference's kernel-variant switches (config.h:60-66, phi.cc:608-700) -- same rules as the C++ host
+    (host/operators.cc CheckedPhiConfig): the work-group modes are one kernel family here (same arithmetic, lane map and
+    streams); PHI_NODE_PER_THREAD (one stream per node, phi.cc:124-152) is refused; phi_vector_width > 1 (Floatn column
+    ownership, phi.cc:214-275) is NOT reproduced and says so."""
+    import warnings
+    mode = str(cfg.phi_mode)
+    mode = {"THREAD": "PHI_NODE_PER_THREAD", "WG-NAIVE": "PHI_NODE_PER_WORKGROUP_NAIVE", "WG-SHARED": "PHI_NODE_PER_WORKGROUP_SHARED",
+            "WG-GEN": "PHI_NODE_PER_WORKGROUP_CODE_GEN"}.get(mode.upper(), mode)  # the CLI's tokens, config.cc:118-131
+    if mode == "PHI_NODE_PER_THREAD":
+        raise AmmsbError("phi_mode PHI_NODE_PER_THREAD is the reference's CPU-device kernel (one RNG stream per node, "
+                         "phi.cc:124-152): no MI355X form; use a PHI_NODE_PER_WORKGROUP_* mode")
+    if mode not in ("PHI_NODE_PER_WORKGROUP_NAIVE", "PHI_NODE_PER_WORKGROUP_SHARED", "PHI_NODE_PER_WORKGROUP_CODE_GEN"):
+        raise AmmsbError("Invalid phi mode: %s" % mode)  # config.cc:118-131
+    if mode != "PHI_NODE_PER_WORKGROUP_NAIVE":
+        warnings.warn("phi_mode %s: runs the PHI_NODE_PER_WORKGROUP_NAIVE kernel family (same arithmetic, lane-to-column "
+                      "map and RNG streams)" % mode)
+    if int(cfg.phi_vector_width) != 1:
+        warnings.warn("phi_vector_width %d: NOT reproduced -- results follow phi_vector_width 1 (the reference's Floatn "
+                      "column ownership, phi.cc:214-275, changes WG_SUM's association and the stream-to-column map)"
+                      % int(cfg.phi_vector_width))
+    if int(cfg.sum_grads_vector_width) != 1:
+        warnings.warn("sum_grads_vector_width %d: accepted; it only widens sum_grads' loads (beta.cc:39-49), the sums "
+                      "are the same" % int(cfg.sum_grads_vector_width))
+
+
 class Sample:
     """sample.h:51-92: one of the two mini-batch buffers with its own queue (stream)."""
 
@@ -133,6 +159,7 @@ class Learner:
         self.rank, self.world, self.group = int(rank), int(world_size), group
         self.sharded = self.world > 1 or bool(getattr(cfg, "force_exchange", False))
         cfg.N, cfg.E = dataset.N, dataset.E
+        _check_kernel_variant_knobs(cfg)
         if cfg.alpha == 0:
             cfg.alpha = float(np.float32(1.0) / np.float32(cfg.K))  # main.cc:153
         self.params = ops.make_params(cfg.N, cfg.K, cfg.E, cfg.num_node_sample, cfg.alpha, cfg.a, cfg.b, cfg.c,
@@ -578,14 +605,14 @@ class Learner:
         H = calc.num_edges
         per = (H + self.world - 1) // self.world
         lo, hi = min(self.rank * per, H), min((self.rank + 1) * per, H)
-        sums = calc.partial(lo, hi)
         if self.sharded:
+            sums = calc.partial(lo, hi)
             dist = self._dist()
             self.ops.all_gather_flat(dist, self.all_sums, sums, self.rank, self.world, self.group)
             parts = [calc.unpack(self.all_sums[r]) for r in range(self.world)]
             tot = [sum(p[i] for p in parts) for i in range(4)]
         else:
-            tot = calc.unpack(sums)
+            tot = calc.partial_host(lo, hi) if hasattr(calc, "partial_host") else calc.unpack(calc.partial(lo, hi))
         ppx = float(np.exp(np.float32(calc.value(*tot))))  # learner.cc:202 std::exp(ppx)
         self.time += time.perf_counter() - t1
         return ppx

@@ -418,16 +418,30 @@ class PerplexityCalculator:
         self.num_edges = int(edges.numel())
         self.ppx_per_edge = ctx.zeros((max(self.num_edges, 1),), torch.float32)  # perplexity.cc:204-205
         self.sums = ctx.zeros((4,), torch.int64)  # ammsb_ppx_sums
+        # the same 32 bytes in host-mapped pinned memory: the kernel writes its result where the host reads it, so a
+        # call is one launch and one stream synchronisation (no device-to-host copy)
+        self.host_sums = torch.zeros((4,), dtype=torch.int64, pin_memory=True)
         self.count_calls = 0
 
-    def partial(self, edge_begin=0, edge_end=0xFFFFFFFF):
+    def partial(self, edge_begin=0, edge_end=0xFFFFFFFF, out=None):
         """Enqueue one pass over edges [edge_begin, edge_end); returns the device sums tensor."""
         c = self.ctx
+        out = self.sums if out is None else out
         c.check(c.lib.ammsb_perplexity(c.handle, _ptr(self.beta), C.byref(self.pi.desc), C.byref(self.set.desc),
                                        _ptr(self.edges), self.num_edges, int(edge_begin),
                                        int(min(edge_end, self.num_edges)), self.count_calls, self.local,
-                                       _ptr(self.ppx_per_edge), _ptr(self.sums), _stream()))
-        return self.sums
+                                       _ptr(self.ppx_per_edge), _ptr(out), _stream()))
+        return out
+
+    def partial_host(self, edge_begin=0, edge_end=0xFFFFFFFF):
+        """One pass with the sums written straight into pinned host memory; waits for the stream and returns
+        (link_ll, nonlink_ll, link_cnt, nonlink_cnt)."""
+        self.partial(edge_begin, edge_end, out=self.host_sums)
+        torch.cuda.current_stream().synchronize()
+        raw = self.host_sums.numpy()
+        ll = raw[:2].view(np.float64)
+        cnt = raw[2:].view(np.uint64)
+        return float(ll[0]), float(ll[1]), int(cnt[0]), int(cnt[1])
 
     @staticmethod
     def unpack(sums):
@@ -445,7 +459,7 @@ class PerplexityCalculator:
 
     def __call__(self):
         self.count_calls += 1  # perplexity.cc:252
-        return self.value(*self.unpack(self.partial()))
+        return self.value(*self.partial_host())
 
 
 MB_CHOICE_DT = np.dtype([("link", np.uint32), ("u", np.uint32), ("n", np.uint32), ("n_candidates", np.uint32)])
@@ -772,6 +786,31 @@ def elapsed_ms(fn):
 
 def pinned(shape, dtype):
     return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+
+class ClockProbe:
+    """ammsb_clock_probe: the shader clock every XCD holds while something else runs.  launch() enqueues the probe
+    blocks on the probe's own stream (beside whatever the caller has in flight); read() waits for them and returns
+    {"mhz_per_xcd": [...], "mhz": median, "blocks": n}."""
+
+    def __init__(self, ctx, n_blocks=64):
+        self.ctx, self.n = ctx, int(n_blocks)
+        self.buf = ctx.zeros((self.n, 3), torch.int64)
+        self.stream = torch.cuda.Stream(device=ctx.device)
+        self.done = torch.cuda.Event()
+
+    def launch(self, spin_us=200):
+        c = self.ctx
+        c.check(c.lib.ammsb_clock_probe(c.handle, _ptr(self.buf), self.n, int(spin_us), C.c_void_p(self.stream.cuda_stream)))
+        self.done.record(self.stream)
+
+    def read(self):
+        self.done.synchronize()
+        t = self.buf.cpu().numpy().astype(np.float64)
+        ok = t[:, 1] > 0
+        mhz = t[ok, 0] / t[ok, 1] * 100.0
+        per = [round(float(np.median(mhz[t[ok, 2] == x])), 1) if (t[ok, 2] == x).any() else None for x in range(8)]
+        return {"mhz_per_xcd": per, "mhz": round(float(np.median(mhz)), 1) if mhz.size else None, "blocks": int(ok.sum())}
 
 
 def _via_host(dist, group):

@@ -152,6 +152,17 @@ int orc_host_sample(uint64_t N, uint64_t E, uint64_t mini_batch, int strategy, u
                     uint64_t* edges_out, uint64_t edges_cap, uint64_t* n_edges, uint32_t* nodes_out,
                     uint64_t nodes_cap, uint64_t* n_nodes, float* weight);
 
+/* ---- the DEVICE mini-batch sampler (csrc/ammsb_minibatch.hip) restated serially: streams, draw, validity,
+ * first-occurrence de-duplication, candidate order, padding, weight (ammsb_oracle_samplers.c has the statement) ---- */
+void orc_rng_init_mixed(orc_seed_t* seeds, uint64_t n, uint64_t sx, uint64_t sy);
+int orc_device_minibatch_nonlink(orc_seed_t* seeds, uint32_t n_candidates, uint32_t u, uint32_t m, uint64_t N,
+                                 const uint64_t* tr_slots, uint64_t tr_bins, uint32_t tr_prime,
+                                 const uint64_t* ho_slots, uint64_t ho_bins, uint32_t ho_prime, uint64_t* edges_out,
+                                 uint32_t* nodes_out, uint32_t* count_out);
+int orc_device_minibatch_link(const uint64_t* csr_offsets, const uint32_t* csr_targets, uint32_t u, uint64_t* edges_out,
+                              uint32_t* nodes_out, uint32_t* n_out);
+float orc_device_minibatch_weight(int link, uint64_t N, uint64_t E, uint32_t m);
+
 /* number of OpenMP threads the library will use (1 if built without OpenMP) */
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

@@ -411,3 +411,97 @@ int orc_host_sample(uint64_t N, uint64_t E, uint64_t mini_batch, int strategy, u
   graph_free(&g);
   return rc;
 }
+
+/* =====================================================================================================
+ * The DEVICE mini-batch sampler (mcmc-ammsb-gpu_amd/csrc/ammsb_minibatch.hip), restated serially.
+ *
+ * It replaces sampleNodeLink / sampleNodeNonLink + ExtractNodesFromMiniBatch (sample.cc:249-293,
+ * learner.cc:162-173) with its OWN random streams, so it has no reference output to equal; what it must equal is
+ * this statement of its algorithm, bit for bit (tests/test_gpu_minibatch_oracle.py):
+ *
+ *   streams     candidate j owns xorshift128+ stream j, states {mix(sx + 2j), mix(sy + 2j + 1)}, mix = the SplitMix64
+ *               finaliser (ammsb_rng_init_mixed), all-zero state replaced by {1, 0};
+ *   draw        v_j = rand(stream j) mod N                     -- one draw per candidate per call, stream advanced;
+ *   validity    v_j != u, (u, v_j) in neither the training nor the held-out set   (sample.cc:283-285; the reference's
+ *               loop also lets v == u through -- its `Vs` is never filled -- which this sampler does not);
+ *   de-dup      a valid candidate is kept iff no valid candidate with a smaller index drew the same v (the reference's
+ *               std::unordered_set<Edge> keeps one copy of an edge; which copy is immaterial there);
+ *   order       kept candidates in candidate order; the first m are the mini-batch: edges[r] = MakeEdge(min, max),
+ *               nodes = {u, v_0, v_1, ...}  (learner.cc:162-173 builds the node list from the edges; here the edge list
+ *               is node-stratified by construction: edge r joins nodes[0] and nodes[r + 1]);
+ *   count       count_out[0] = kept candidates (may exceed m); fewer than m: the tail repeats earlier entries
+ *               (edges[r] = edges[r mod count]) so that the buffers stay valid, and the caller is told (count < m);
+ *   weight      link: N (sample.cc:268); non-link: 2 E / m (sample.cc:292), both as float.
+ * ===================================================================================================== */
+
+static uint64_t dev_splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+void orc_rng_init_mixed(orc_seed_t* seeds, uint64_t n, uint64_t sx, uint64_t sy) {
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t x = dev_splitmix64(sx + 2 * i), y = dev_splitmix64(sy + 2 * i + 1);
+    if ((x | y) == 0) x = 1;
+    seeds[i].x = x;
+    seeds[i].y = y;
+  }
+}
+
+int orc_device_minibatch_nonlink(orc_seed_t* seeds, uint32_t n_candidates, uint32_t u, uint32_t m, uint64_t N,
+                                 const uint64_t* tr_slots, uint64_t tr_bins, uint32_t tr_prime,
+                                 const uint64_t* ho_slots, uint64_t ho_bins, uint32_t ho_prime, uint64_t* edges_out,
+                                 uint32_t* nodes_out, uint32_t* count_out) {
+  if (!seeds || !tr_slots || !edges_out || !nodes_out || !count_out || m == 0 || N == 0 || u >= N) return -1;
+  uint32_t* first = (uint32_t*)malloc(sizeof(uint32_t) * N); /* first[v] = 1 + smallest valid candidate that drew v */
+  if (!first) return -1;
+  memset(first, 0, sizeof(uint32_t) * N);
+  uint32_t kept = 0;
+  nodes_out[0] = u;
+  for (uint32_t j = 0; j < n_candidates; ++j) {
+    const uint32_t v = (uint32_t)(orc_rand(&seeds[j]) % N);
+    if (v == u) continue;
+    const uint64_t a = u < v ? u : v, b = u < v ? v : u;
+    const uint64_t e = (a << 32) | b;
+    if (orc_set_has(tr_slots, tr_bins, tr_prime, e)) continue;
+    if (ho_slots && orc_set_has(ho_slots, ho_bins, ho_prime, e)) continue;
+    if (first[v]) continue; /* an earlier valid candidate has this partner */
+    first[v] = j + 1;
+    if (kept < m) {
+      edges_out[kept] = e;
+      nodes_out[1 + kept] = v;
+    }
+    ++kept;
+  }
+  free(first);
+  count_out[0] = kept;
+  if (kept < m && kept > 0) {
+    for (uint32_t r = kept; r < m; ++r) {
+      edges_out[r] = edges_out[r % kept];
+      nodes_out[1 + r] = nodes_out[1 + r % kept];
+    }
+  }
+  return 0;
+}
+
+/* all training edges (u, v) of u, v in CSR (adjacency) order: sampleNodeLink's edge set for one u (sample.cc:252-266) */
+int orc_device_minibatch_link(const uint64_t* csr_offsets, const uint32_t* csr_targets, uint32_t u, uint64_t* edges_out,
+                              uint32_t* nodes_out, uint32_t* n_out) {
+  if (!csr_offsets || !csr_targets || !edges_out || !nodes_out || !n_out) return -1;
+  const uint64_t lo = csr_offsets[u], hi = csr_offsets[u + 1];
+  nodes_out[0] = u;
+  for (uint64_t t = lo; t < hi; ++t) {
+    const uint32_t v = csr_targets[t];
+    const uint64_t a = u < v ? u : v, b = u < v ? v : u;
+    edges_out[t - lo] = (a << 32) | b;
+    nodes_out[1 + (t - lo)] = v;
+  }
+  *n_out = (uint32_t)(hi - lo);
+  return 0;
+}
+
+float orc_device_minibatch_weight(int link, uint64_t N, uint64_t E, uint32_t m) {
+  return link ? (float)N : (float)(2 * E) / (float)m;
+}

@@ -221,7 +221,59 @@ def _bind_samplers(L):
                                   u64p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
                                   u64p, C.c_uint64, C.POINTER(C.c_uint64), u32p, C.c_uint64, C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_float)]
+    L.orc_rng_init_mixed.restype = None
+    L.orc_rng_init_mixed.argtypes = [np.ctypeslib.ndpointer(SEED_DT, flags="C"), C.c_uint64, C.c_uint64, C.c_uint64]
+    L.orc_device_minibatch_nonlink.restype = C.c_int
+    L.orc_device_minibatch_nonlink.argtypes = [np.ctypeslib.ndpointer(SEED_DT, flags="C"), C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.c_uint64, u64p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
+                                               u64p, u32p, u32p]
+    L.orc_device_minibatch_link.restype = C.c_int
+    L.orc_device_minibatch_link.argtypes = [u64p, u32p, C.c_uint32, u64p, u32p, u32p]
+    L.orc_device_minibatch_weight.restype = C.c_float
+    L.orc_device_minibatch_weight.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32]
     return L
+
+
+def rng_init_mixed(n, sx, sy):
+    """ammsb_rng_init_mixed restated: SplitMix64-scrambled stream states."""
+    L = _bind_samplers(lib())
+    seeds = np.zeros(n, dtype=SEED_DT)
+    L.orc_rng_init_mixed(seeds, n, sx, sy)
+    return seeds
+
+
+def device_minibatch_nonlink(seeds, n_candidates, u, m, N, tset, hset):
+    """The device sampler's non-link half restated (oracle/ammsb_oracle_samplers.c): advances seeds[:n_candidates] in
+    place; returns (edges [m], nodes [m + 1], distinct valid candidates found)."""
+    L = _bind_samplers(lib())
+    e = np.zeros(m, dtype=np.uint64)
+    v = np.zeros(m + 1, dtype=np.uint32)
+    cnt = np.zeros(1, dtype=np.uint32)
+    ho = hset.slots.ctypes.data if hset is not None else None
+    rc = L.orc_device_minibatch_nonlink(seeds, n_candidates, u, m, N, tset.slots, tset.num_bins, tset.prime_idx, ho,
+                                        hset.num_bins if hset is not None else 0,
+                                        hset.prime_idx if hset is not None else 0, e, v, cnt)
+    if rc != 0:
+        raise RuntimeError("orc_device_minibatch_nonlink rc=%d" % rc)
+    return e, v, int(cnt[0])
+
+
+def device_minibatch_link(offsets, targets, u):
+    L = _bind_samplers(lib())
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    targets = np.ascontiguousarray(targets, dtype=np.uint32)
+    n = int(offsets[u + 1] - offsets[u])
+    e = np.zeros(max(n, 1), dtype=np.uint64)
+    v = np.zeros(n + 1, dtype=np.uint32)
+    cnt = np.zeros(1, dtype=np.uint32)
+    rc = L.orc_device_minibatch_link(offsets, targets, u, e, v, cnt)
+    if rc != 0:
+        raise RuntimeError("orc_device_minibatch_link rc=%d" % rc)
+    return e[:n], v, int(cnt[0])
+
+
+def device_minibatch_weight(link, N, E, m):
+    return float(_bind_samplers(lib()).orc_device_minibatch_weight(int(bool(link)), N, E, m))
 
 
 def uset_order(keys):

@@ -173,3 +173,48 @@ def test_print_stats_categories_in_the_enqueue_only_loops(exe, tmp_path, loop):
     assert cat(off.stderr, "PHI") == 0 and cat(off.stderr, "GRADS PAR") == 0
     # the trajectory does not depend on the timers
     assert _ppx_lines(off.stderr) == _ppx_lines(run.stderr)
+
+
+@pytest.mark.gpu
+def test_kernel_variant_flags_are_not_ignored_silently(exe, tmp_path):
+    """main.cc:71-76 / phi.cc:608-700: --phi-mode PHI_NODE_PER_THREAD (another stream map) is refused; --phi-vwidth > 1
+    (another column ownership) runs the width-1 form and SAYS so; the SHARED / CODE_GEN modes and
+    --beta-sum-grads-vwidth are the same arithmetic and give the same trajectory, with a line naming what ran."""
+    g, d = str(tmp_path / "g.txt"), str(tmp_path / "g.bin.gz")
+    _snap_file(g)
+    r = subprocess.run([exe, "-f", g, "--dump-data", "1", "--dump-file", d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    common = [exe, "--load-data", "1", "--load-file", d, "-k", "64", "-m", "128", "-n", "16", "-r", "0.05", "-x", "20", "-i", "20"]
+    base = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert base.returncode == 0 and "\nW " not in base.stderr, base.stderr[-2000:]
+    thr = subprocess.run(common + ["--phi-mode", "THREAD"], capture_output=True, text=True, timeout=600)
+    assert thr.returncode == 2 and "PHI_NODE_PER_THREAD" in thr.stderr and "F " in thr.stderr, thr.stderr[-2000:]
+    vw = subprocess.run(common + ["--phi-vwidth", "4"], capture_output=True, text=True, timeout=600)
+    assert vw.returncode == 0 and re.search(r"^W phi_vector_width 4: NOT reproduced", vw.stderr, re.M), vw.stderr[-2000:]
+    assert _ppx_lines(vw.stderr) == _ppx_lines(base.stderr)  # it is the width-1 trajectory, as the line says
+    sh = subprocess.run(common + ["--phi-mode", "WG-SHARED", "--beta-sum-grads-vwidth", "4"],
+                        capture_output=True, text=True, timeout=600)
+    assert sh.returncode == 0 and re.search(r"^W phi_mode WG-SHARED", sh.stderr, re.M), sh.stderr[-2000:]
+    assert re.search(r"^W sum_grads_vector_width 4", sh.stderr, re.M) and _ppx_lines(sh.stderr) == _ppx_lines(base.stderr)
+    bad = subprocess.run(common + ["--phi-mode", "PHI_NODE_PER_THREAD"], capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 2 and "invalid" in bad.stderr  # (the CLI tokens are THREAD / WG-NAIVE / WG-SHARED / WG-GEN, config.cc:118-131)
+
+
+def test_python_config_refuses_per_thread_mode_and_warns_on_vector_width():
+    import warnings
+    import ammsb_pkg
+    ammsb_pkg.load()
+    from mcmc_ammsb_gpu_amd import learner
+    from mcmc_ammsb_gpu_amd._capi import AmmsbError
+    with pytest.raises(AmmsbError, match="PHI_NODE_PER_THREAD"):
+        learner._check_kernel_variant_knobs(learner.Config(phi_mode="PHI_NODE_PER_THREAD"))
+    with pytest.raises(AmmsbError, match="Invalid phi mode"):
+        learner._check_kernel_variant_knobs(learner.Config(phi_mode="WHATEVER"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        learner._check_kernel_variant_knobs(learner.Config(phi_vector_width=2, phi_mode="PHI_NODE_PER_WORKGROUP_CODE_GEN"))
+    assert any("NOT reproduced" in str(x.message) for x in w) and any("CODE_GEN" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        learner._check_kernel_variant_knobs(learner.Config())
+    assert not w

@@ -59,4 +59,25 @@ for k in range(min(steps, 16)):
     print("  step %2d: since the last stamp +%5d | requests + keys +%5d | wait for rows +%5d %s" % (k, a - prev, b - a, c - b, tail))
     prev = d if d > c else c
 print("steps", steps, "| whole wave", t[4] - t[0], "cycles")
+# per-block record of the last launch: is the launch one round of resident waves?
+if hasattr(lib, "ammsb_debug_blocks_beta"):
+    lib.ammsb_debug_blocks_beta.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    nb = min(ne, 2048)
+    bb = (C.c_ulonglong * (5 * nb))()
+    assert lib.ammsb_debug_blocks_beta(bb, nb) == 0
+    q = np.frombuffer(bb, dtype=np.uint64).reshape(nb, 5).astype(np.int64)
+    c0, c1, w0, w1, hw = (q[:, i] for i in range(5))
+    T0 = w0.min()
+    ok = (w1 - w0) > 100
+    print("blocks %d | launch span %.1f us (first block start -> last block end, wall clock) | shader clock %.0f MHz" % (
+        nb, (w1.max() - T0) / 100.0, float(np.median((c1 - c0)[ok] / ((w1 - w0)[ok] / 100.0)))))
+    print("block start us: p0 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile((w0 - T0) / 100.0, [0, 50, 90, 99, 100])))
+    print("block life  us: p0 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | cycles p50 %d" % (tuple(np.percentile((w1 - w0) / 100.0, [0, 50, 90, 99, 100])) + (int(np.median(c1 - c0)),)))
+    xcc = (hw >> 32) & 0xf
+    hwid = hw & 0xffffffff
+    cukey = xcc * 1000 + ((hwid >> 13) & 7) * 100 + ((hwid >> 12) & 1) * 50 + ((hwid >> 8) & 0xf)
+    per_cu = np.bincount(np.unique(cukey, return_inverse=True)[1])
+    print("distinct CUs %d | blocks per CU: min %d median %d max %d" % (per_cu.size, per_cu.min(), np.median(per_cu), per_cu.max()))
+    edges_t = np.arange(0, (w1.max() - T0) + 200, 200)
+    print("resident blocks every 2 us:", [int(((w0 - T0) <= e).sum() - ((w1 - T0) <= e).sum()) for e in edges_t])
 PY
