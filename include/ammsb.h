@@ -277,7 +277,10 @@ typedef struct {
   uint32_t link, u, n, n_candidates;
 } ammsb_mb_choice;
 
-/* Captures the graphs; every buffer in cfg must stay valid (and keep its address) until ammsb_loop_destroy. */
+/* Captures the graphs; every buffer in cfg must stay valid (and keep its address) until ammsb_loop_destroy.
+ * edges[] / nodes[] / neighbors[] / nbr_table[] must be 16-byte aligned (AMMSB_EINVAL otherwise): a run that ends with
+ * its pending mini-batch in the loop's own third buffer set moves it into the caller's with 16-byte words -- exactly
+ * the mini-batch's bytes, nothing beyond them, so the four buffers may be carved back to back from one allocation. */
 int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, ammsb_loop** out);
 int ammsb_loop_destroy(ammsb_loop* loop);
 /* Enqueue n_steps iterations behind the work already queued on `stream` (and make `stream` wait for them).

@@ -99,6 +99,7 @@ class Learner {
   bool consumed_valid_[2] = {false, false};
   void* ev_sampler_ = nullptr;  // the device sampler's shared streams / workspace: one call at a time
   bool sampler_valid_ = false;
+  uint32_t chunks_since_check_ = 0;  // RunGraph: chunks enqueued since the last ammsb_loop_check
   bool enqueued_[2] = {false, false};
   Float weights_[2] = {0, 0};
   ammsb_mb_choice choice_[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // what sits in each sample's buffers (device sampling)

@@ -118,10 +118,16 @@ __global__ void loop_bump_kernel(uint32_t* counter, const ammsb_step_desc* desc)
 
 // the run's epilogue copy of the pending mini-batch into the caller's buffer set -- unless the run is poisoned (the
 // source may then not have been sampled, and the destination may hold a mini-batch the resumed run still needs)
-__global__ void loop_copy_kernel(uint4* dst, const uint4* src, size_t n16, const uint32_t* timeouts) {
+// Exactly `bytes` bytes (a multiple of 4: the buffers hold u32 / u64 items): whole 16-byte chunks, then the tail word by
+// word -- nothing past the declared size is written, so a caller may carve its buffers back to back from one allocation.
+// dst / src are 16-byte aligned (checked by ammsb_loop_create; the loop's own set is 256-byte aligned).
+__global__ void loop_copy_kernel(uint4* dst, const uint4* src, size_t bytes, const uint32_t* timeouts) {
   if (timeouts && *timeouts != 0u) return;
+  const size_t n16 = bytes / 16;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < (bytes % 16) / 4)
+    reinterpret_cast<uint32_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint32_t*>(src + n16)[threadIdx.x];
 }
 
 // create-time probe: can a kernel on one stream run while a kernel on the other is spinning?
@@ -387,6 +393,10 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
   for (int i = 0; i < 2; ++i)
     AMMSB_CHECK_ARG(ctx, c.edges[i] && c.nodes[i] && c.neighbors[i] && c.nbr_table[i] && c.nbr_seeds[i],
                     "null sample buffer");
+  for (int i = 0; i < 2; ++i)  // the hand-back of the pending mini-batch moves 16-byte words (loop_copy_kernel)
+    AMMSB_CHECK_ARG(ctx, ((reinterpret_cast<uintptr_t>(c.edges[i]) | reinterpret_cast<uintptr_t>(c.nodes[i]) |
+                           reinterpret_cast<uintptr_t>(c.neighbors[i]) | reinterpret_cast<uintptr_t>(c.nbr_table[i])) & 15u) == 0,
+                    "edges / nodes / neighbors / nbr_table must be 16-byte aligned");
   AMMSB_CHECK_ARG(ctx, c.csr_offsets && c.csr_targets && c.mb_seeds && c.mb_workspace && c.mb_count,
                   "null mini-batch sampler buffer");
   AMMSB_CHECK_ARG(ctx, c.mini_batch > 0 && c.max_fan_out > 0, "mini_batch / max_fan_out must be positive");
@@ -488,7 +498,13 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
       CREATE_HIP(hipMemcpy(&saw, probe + 1, sizeof saw, hipMemcpyDeviceToHost));
       if (!saw) lp->use_events = true;
     }
-    if (const char* f = getenv("AMMSB_LOOP_TEST_FAIL_AT")) lp->test_fail_at = (uint32_t)atoi(f);
+    if (const char* f = getenv("AMMSB_LOOP_TEST_FAIL_AT")) {  // (test hook: never set in a job's environment)
+      const long v = strtol(f, nullptr, 10);
+      if (v > 0) {
+        lp->test_fail_at = (uint32_t)v;
+        fprintf(stderr, "ammsb_loop: AMMSB_LOOP_TEST_FAIL_AT=%ld -- the sampler chain of mini-batch %ld will be made to give up (fault injection)\n", v, v);
+      }
+    }
     lp->host_prof = getenv("AMMSB_LOOP_HOSTPROF") != nullptr;
     const char* lm = getenv("AMMSB_LOOP_LAUNCH");
     lp->serial_launch = lm && strcmp(lm, "serial") == 0;
@@ -496,8 +512,16 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     int khz = 100000;
     CREATE_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
     lp->wait_ticks = 5000ull * (unsigned long long)(khz > 0 ? khz : 100000);  // 5 s
-    if (const char* w = getenv("AMMSB_LOOP_WAIT_MS"))  // (tests: a short give-up time)
-      lp->wait_ticks = (unsigned long long)atoi(w) * (unsigned long long)(khz > 0 ? khz : 100000);
+    if (const char* w = getenv("AMMSB_LOOP_WAIT_MS")) {  // (tests: a short give-up time)
+      char* end = nullptr;
+      const long ms = strtol(w, &end, 10);
+      if (end == w || *end != '\0' || ms < 1 || ms > 600000) {
+        fprintf(stderr, "ammsb_loop: AMMSB_LOOP_WAIT_MS='%s' ignored (want 1 .. 600000); waits give up after 5 s\n", w);
+      } else {
+        lp->wait_ticks = (unsigned long long)ms * (unsigned long long)(khz > 0 ? khz : 100000);
+        fprintf(stderr, "ammsb_loop: AMMSB_LOOP_WAIT_MS=%ld -- device-side waits give up after %ld ms\n", ms, ms);
+      }
+    }
   }
   for (Stage& st : lp->stage) {
     CREATE_HIP(hipHostMalloc(&st.ring, sizeof(ammsb_step_desc) * (CHUNK + 4), hipHostMallocDefault));
@@ -712,13 +736,13 @@ int submit(ammsb_loop* lp, const ammsb_mb_choice* pending, const ammsb_mb_choice
     const ammsb_mb_choice& ch = choice(n_steps);
     const size_t ne = ch.link ? ch.n : lp->c.mini_batch, nv = ne + 1;
     const SampleBuf &a = lp->buf[from], &b = lp->buf[to];
-    // (kernels, not copy commands: a poisoned run must leave the destination alone -- see loop_copy_kernel; the
-    // buffers are whole allocations, so rounding the sizes up to 16 bytes stays inside them)
+    // (kernels, not copy commands: a poisoned run must leave the destination alone -- see loop_copy_kernel, which
+    // copies exactly the bytes named)
     const uint32_t* poison = ev ? nullptr : lp->d_hs + HS_TIMEOUTS;
     auto copy = [&](void* dst, const void* src, size_t bytes) {
-      const size_t n16 = (bytes + 15) / 16;
+      const size_t n16 = bytes / 16;
       const unsigned blocks = (unsigned)(n16 / 256 + 1 < 1024 ? n16 / 256 + 1 : 1024);
-      loop_copy_kernel<<<blocks, 256, 0, lp->main>>>(static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16, poison);
+      loop_copy_kernel<<<blocks, 256, 0, lp->main>>>(static_cast<uint4*>(dst), static_cast<const uint4*>(src), bytes, poison);
     };
     copy(b.edges, a.edges, sizeof(uint64_t) * ne);
     copy(b.nodes, a.nodes, sizeof(uint32_t) * nv);

@@ -77,10 +77,26 @@ struct Star {
       const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
       if (ls < 0) Fail("socket()");
       setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-      // listen on MASTER_ADDR only (loopback for a single node): nothing outside the job's own network can connect
-      if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof sa) != 0)
-        Fail("bind() on the exchange port " + std::to_string(port) +
-             " failed (MASTER_PORT + 1 taken? pass a free AMMSB_EXCHANGE_PORT to every rank)");
+      // listen on MASTER_ADDR only (loopback for a single node): nothing outside the job's own network can connect.
+      // AMMSB_EXCHANGE_BIND names another local address to listen on ("0.0.0.0" = every interface); and when
+      // MASTER_ADDR is reachable by the peers without being an address of THIS host (a NAT / service address, a
+      // forwarded container port: EADDRNOTAVAIL) the listener falls back to every interface, saying so.
+      sockaddr_in la = sa;
+      if (const char* b = getenv("AMMSB_EXCHANGE_BIND")) {
+        if (*b && inet_pton(AF_INET, b, &la.sin_addr) != 1) Fail("AMMSB_EXCHANGE_BIND must be an IPv4 address");
+      }
+      int brc = ::bind(ls, reinterpret_cast<sockaddr*>(&la), sizeof la);
+      if (brc != 0 && errno == EADDRNOTAVAIL) {
+        fprintf(stderr, "W mcmc::Exchange: %s is not an address of this host; listening on every interface (port %d)\n",
+                addr.c_str(), port);
+        la.sin_addr.s_addr = htonl(INADDR_ANY);
+        brc = ::bind(ls, reinterpret_cast<sockaddr*>(&la), sizeof la);
+      }
+      if (brc != 0) {
+        const int err = errno;
+        Fail("bind() to " + addr + ":" + std::to_string(port) + " failed: " + strerror(err) +
+             (err == EADDRINUSE ? " (MASTER_PORT + 1 taken? pass a free AMMSB_EXCHANGE_PORT to every rank)" : ""));
+      }
       if (::listen(ls, world) != 0) Fail("listen()");
       fds.assign(world, -1);
       // the peers retry for a minute; so does this side: a rank that died before connecting must not hang rank 0

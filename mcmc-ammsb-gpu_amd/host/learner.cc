@@ -527,6 +527,13 @@ void Learner::RunGraph(uint32_t max_iters, sig_atomic_t* signaled) {
     clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_sampler_), main), "hipEventRecord");
     sampler_valid_ = true;
     done += n;
+    // every 64 chunks (32 768 iterations) the loop's record of what it has enqueued is released and a device-side
+    // wait that gave up is noticed and resumed (ammsb_loop_check synchronises): a long Run() neither grows that
+    // record without bound nor learns about a fallback only at its very end
+    if (++chunks_since_check_ >= 64) {
+      chunks_since_check_ = 0;
+      CheckDeviceSampler();
+    }
   }
 }
 

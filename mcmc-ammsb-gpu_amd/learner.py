@@ -528,6 +528,12 @@ class Learner:
                 o.consumed_valid = True
             smp.mark_used()
             done += n
+            # every 64 chunks the loop's record of what it has enqueued is released and a fallback is noticed
+            # (ammsb_loop_check synchronises): a long Run() does not grow that record without bound
+            self._chunks_since_check = getattr(self, "_chunks_since_check", 0) + 1
+            if self._chunks_since_check >= 64:
+                self._chunks_since_check = 0
+                self._check_loop()
         self.time += time.perf_counter() - t1
 
     def _run(self, max_iters, signaled=None):

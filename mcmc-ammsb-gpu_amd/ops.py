@@ -417,16 +417,18 @@ class PerplexityCalculator:
         self.local = int(ppx_wg_size)
         self.num_edges = int(edges.numel())
         self.ppx_per_edge = ctx.zeros((max(self.num_edges, 1),), torch.float32)  # perplexity.cc:204-205
-        self.sums = ctx.zeros((4,), torch.int64)  # ammsb_ppx_sums
+        self.dev_sums = ctx.zeros((4,), torch.int64)  # ammsb_ppx_sums
         # the same 32 bytes in host-mapped pinned memory: the kernel writes its result where the host reads it, so a
         # call is one launch and one stream synchronisation (no device-to-host copy)
         self.host_sums = torch.zeros((4,), dtype=torch.int64, pin_memory=True)
+        self.sums = self.dev_sums  # where the last pass put its result (device tensor, or host_sums after operator())
         self.count_calls = 0
 
     def partial(self, edge_begin=0, edge_end=0xFFFFFFFF, out=None):
-        """Enqueue one pass over edges [edge_begin, edge_end); returns the device sums tensor."""
+        """Enqueue one pass over edges [edge_begin, edge_end); returns the sums tensor (device memory unless `out`)."""
         c = self.ctx
-        out = self.sums if out is None else out
+        out = self.dev_sums if out is None else out
+        self.sums = out
         c.check(c.lib.ammsb_perplexity(c.handle, _ptr(self.beta), C.byref(self.pi.desc), C.byref(self.set.desc),
                                        _ptr(self.edges), self.num_edges, int(edge_begin),
                                        int(min(edge_end, self.num_edges)), self.count_calls, self.local,

@@ -102,3 +102,59 @@ def test_golden_host_sampler_vectors(orc):
     assert set(now) == set(g.files)
     for k in g.files:
         assert np.array_equal(g[k], now[k]), k
+
+
+def test_device_sampler_statement_properties(orc, dataset):
+    """The serial statement of the DEVICE sampler (row f1; the -m gpu suite compares the kernels with it bit for bit):
+    checked here against its own definition with numpy -- draw = rand(stream j) mod N, validity, first occurrence among
+    the valid candidates, candidate order, count, padding, weights."""
+    ds = dataset
+    tr, ho = _OSet(ds.training), _OSet(ds.heldout)
+    N, m, C_ = ds.N, 256, 1024
+    seeds = orc.rng_init_mixed(C_, 1234, 5678)
+    s0 = seeds.copy()
+    # the mixed seeding: SplitMix64 finaliser of sx + 2 i / sy + 2 i + 1
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return z ^ (z >> 31)
+    for i in (0, 1, 77, C_ - 1):
+        assert int(s0["x"][i]) == mix(1234 + 2 * i) and int(s0["y"][i]) == mix(5678 + 2 * i + 1)
+    u = 5
+    e, v, cnt = orc.device_minibatch_nonlink(seeds, C_, u, m, N, tr, ho)
+    # the draws, from an independent evaluation of xorshift128+ (random.cl.inc:13-25) on the initial states
+    M = 2**64 - 1
+    draws = []
+    for i in range(C_):
+        s1, s0_ = int(s0["x"][i]), int(s0["y"][i])
+        x = s0_
+        s1 ^= (s1 << 23) & M
+        y = s1 ^ s0_ ^ (s1 >> 17) ^ (s0_ >> 26)
+        draws.append(((y + s0_) & M) % N)
+        assert int(seeds["x"][i]) == x and int(seeds["y"][i]) == y  # every candidate stream advanced by one draw
+    draws = np.array(draws, dtype=np.uint64)
+    keys = orc.make_edge(np.full(C_, u, dtype=np.uint64), draws)
+    valid = (draws != u) & ~ds.training.Has(keys) & ~ds.heldout.Has(keys)
+    seen, kept = set(), []
+    for j in range(C_):
+        if valid[j] and int(draws[j]) not in seen:
+            seen.add(int(draws[j]))
+            kept.append(j)
+    assert cnt == len(kept) >= m
+    assert np.array_equal(v[1:], draws[kept[:m]].astype(np.uint32)) and v[0] == u
+    assert np.array_equal(e, keys[kept[:m]])
+    # shortfall: fewer candidates than needed -> count < m, the tail repeats the head
+    seeds2 = orc.rng_init_mixed(C_, 9, 10)
+    e2, v2, cnt2 = orc.device_minibatch_nonlink(seeds2, 64, u, m, N, tr, ho)
+    assert 0 < cnt2 <= 64 < m
+    assert np.array_equal(e2[cnt2:], e2[np.arange(cnt2, m) % cnt2]) and np.array_equal(v2[1 + cnt2:], v2[1 + np.arange(cnt2, m) % cnt2])
+    # link half and weights (sample.cc:252-268, :292)
+    off, tgt = ds.training_csr()
+    uu = int(np.flatnonzero(np.diff(off.astype(np.int64)) > 2)[0])
+    le, lv, ln = orc.device_minibatch_link(off, tgt, uu)
+    nb = tgt[int(off[uu]):int(off[uu + 1])]
+    assert ln == nb.size and lv[0] == uu and np.array_equal(lv[1:], nb)
+    assert np.array_equal(le, orc.make_edge(np.full(ln, uu, dtype=np.uint64), nb.astype(np.uint64))) and ds.training.Has(le).all()
+    assert orc.device_minibatch_weight(1, N, ds.E, m) == float(np.float32(N))
+    assert orc.device_minibatch_weight(0, N, ds.E, m) == float(np.float32(2 * ds.E) / np.float32(m))
