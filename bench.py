@@ -595,6 +595,26 @@ def main():
         loop_note += "; %d run(s) finished on the stream-event hand-over after a device-side wait gave up" % fallback
     phi_split = None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
                                              groups_per_block=lrn.cc, chunks=lrn.nch)
+    if world > 1:
+        # what makes a multi-GPU line readable by itself: a traced (untimed) window right after the timed one -- per
+        # non-link step where the time went (own blocks, replicated groups, each chunk's exchange and what of it was
+        # hidden, update_pi, the gradient's all-gather), next to the calibration's prediction above
+        try:
+            lrn.shard_trace = []
+            traced = 0
+            while traced < 64 and sum(1 for t_ in lrn.shard_trace if t_["n_nodes"] > m // 2) < 6:
+                lrn.Run(4)
+                traced += 4
+            lrn.drain()
+            rep = lrn.shard_report()
+            lrn.shard_trace = None
+            phi_split["trace"] = rep
+            if rep.get("steps") and phi_split.get("phi_ms"):
+                phi_split["trace"]["predicted_vs_measured"] = {
+                    "predicted_phi_ms": phi_split.get("predicted_phi_ms"), "measured_phi_phase_ms": rep.get("phi_phase_ms"),
+                    "calibrated_full_exchange_ms": phi_split.get("xchg_ms"), "measured_exchange_ms": rep.get("exchange_ms")}
+        except Exception as e:  # diagnostics must not cost the line
+            phi_split["trace"] = {"error": repr(e)}
     lrn.close()
     del lrn
     torch.cuda.empty_cache()

@@ -96,6 +96,13 @@ struct Config {
   // rand() (sample.cc:132), which is not reproducible once the HIP runtime shares the process (its
   // start-up consumes rand() too); the defaults are what rand() returns first after srand(1).
   unsigned int sample_seed[2];
+  // new (multi-GPU, with `exchange`): the sharded update_phi as in mcmc-ammsb-gpu_amd/learner.py -- the first
+  // phi_replicate * 65535 virtual groups are computed by every rank (nothing to send), the rest are cut into
+  // world * phi_chunks blocks whose exchange overlaps the next block's update_phi.  phi_replicate < 0: measured at
+  // start-up (one timed update_phi and one timed all-gather; rank 0's answer is adopted by every rank); 0 = every
+  // group exchanged.
+  uint32_t phi_chunks;
+  Float phi_replicate;
 
   Config();
 };

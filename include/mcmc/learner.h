@@ -104,7 +104,15 @@ class Learner {
   Float weights_[2] = {0, 0};
   ammsb_mb_choice choice_[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // what sits in each sample's buffers (device sampling)
   ammsb_loop* loop_ = nullptr;
-  uint32_t cc_ = 0;  // virtual groups per rank block: rank r owns [r * cc_, (r + 1) * cc_)
+  // Ownership map of the sharded update_phi: groups [0, g_rep_) are replicated (every rank computes them); the rest are
+  // cut into world * nch_ blocks of cc_ groups, block b owned by rank b % world and exchanged in chunk b / world.
+  uint32_t cc_ = 0, g_rep_ = 0, nch_ = 1;
+  void SetSplit(uint32_t g_rep);
+  void CalibrateSplit();              // Config::phi_replicate < 0: balance recomputing a group against receiving it
+  void* xstream_ = nullptr;           // the exchanges of a step run here, beside the next block's update_phi
+  void* ev_block_ = nullptr;          // main stream: a block's update_phi has been enqueued (the exchange waits for it)
+  void* ev_xdone_ = nullptr;          // exchange stream: the step's exchanges are done (the main stream waits for it)
+  double calib_phi_ms_ = 0, calib_xchg_ms_ = 0;
   std::unique_ptr<clcuda::Buffer<Float>> all_grads_, grads_sum_, tail_buf_;
   std::unique_ptr<clcuda::Buffer<ammsb_ppx_sums>> all_sums_;
   std::unique_ptr<Sample> samples_[2];  // MCMC_SAMPLE_PARALLEL (CMakeLists.txt:42, default ON)

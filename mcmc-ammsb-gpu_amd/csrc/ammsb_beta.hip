@@ -15,6 +15,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ammsb_ctx.h"
 #include "ammsb_dev.h"
 #include "ammsb_step.h"
@@ -326,8 +328,11 @@ typedef const __attribute__((address_space(1))) void beta_glb_void_t;
 // values the separate update_pi would have stored: bit-identical, one launch and one pass over the rows less.
 // VL = 32 (W == 1): the reference work-group size is 32 (its default, main.cc:64); the slot keeps its whole wave, the
 // WG_SUM chains / trees follow the 32 virtual lanes (VLane<32>, ammsb_dev.h).
-template <int KPT, int W, bool FUSE = false, int VL = 64>
-__global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a) {
+#ifndef AMMSB_BETA_VGPRS
+#define AMMSB_BETA_VGPRS 256
+#endif
+template <int KPT, int W, bool FUSE, int VL>
+__device__ __forceinline__ void beta_grads_lds_body(const BetaArgs& a) {
   static_assert(!FUSE || W == 1, "the fused form is one wave per slot");
   static_assert(VL == 64 || W == 1, "virtual half-wave lanes only for one-wave slots");
   using VLn = VLane<VL>;
@@ -512,6 +517,32 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     if (gs == 0 && tid == 0) a.fuse.phi_sum[shared_node] = sum;
   }
 
+  // the link flag's picks among the per-column constants; mode 1 / 2 = the flag is known to be false / true (uniform
+  // mini-batches: no select is emitted), mode 0 = decided at run time
+  // (`one`: 1.0f behind an empty asm, refreshed per step by the callers -- written as a literal, 1 - beta_k is loop
+  // invariant and hipcc keeps all KPT of them in registers across the loop: 16 more VGPRs at K = 1024, which drops
+  // the kernel from two waves per SIMD to one)
+  float one = 1.0f;
+  auto sel_b = [&](int p, bool y, auto mode) -> f32x2 {
+    if constexpr (decltype(mode)::value == 1) return one - bk[p];
+    else if constexpr (decltype(mode)::value == 2) return bk[p];
+    else return y ? bk[p] : one - bk[p];
+  };
+  auto sel_0 = [&](int p, bool y, auto mode) -> f32x2 {
+    if constexpr (decltype(mode)::value == 1) return d0n[p];
+    else if constexpr (decltype(mode)::value == 2) return noo[p];
+    else return y ? noo[p] : d0n[p];
+  };
+  auto sel_1 = [&](int p, bool y, auto mode) -> f32x2 {
+    if constexpr (decltype(mode)::value == 1) return noo[p];
+    else if constexpr (decltype(mode)::value == 2) return d1l[p];
+    else return y ? d1l[p] : noo[p];
+  };
+  auto sel_w = [&](bool y, auto mode) -> float {
+    if constexpr (decltype(mode)::value == 1) return 1.0f - EPS;
+    else if constexpr (decltype(mode)::value == 2) return EPS;
+    else return y ? EPS : (1.0f - EPS);
+  };
   if constexpr (!FUSE && W == 1) {
     // TWO edges per step where the slot's consecutive edges share their first end point (every edge of a node-strategy
     // mini-batch does): the chains of edges t and t + 1 -- probs, two WG_SUMs each, reciprocal, division -- are issued
@@ -553,7 +584,9 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       if (pair) {
         const unsigned long long e1 = key_of(t + 1, &y1);
         y1 = __builtin_amdgcn_readfirstlane((int)y1) != 0;
-        pair = __builtin_amdgcn_readfirstlane((uint32_t)(e1 >> 32)) == u0;
+        // (a pair shares its first end point AND its link flag -- every edge of a node-strategy mini-batch does; an odd
+        // one out is reduced alone)
+        pair = __builtin_amdgcn_readfirstlane((uint32_t)(e1 >> 32)) == u0 && y1 == y0;
       }
       BETA_TRACE(8 + 4 * (t / 2) + 1);
       wait_rows(issued - (t + (pair ? 2u : 1u)));
@@ -571,6 +604,11 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       }
       const float* row0 = ring + (t % D) * KW;
       if (pair) {
+        // every edge of a node-strategy mini-batch has the same link flag (a link batch is all links, a non-link
+        // batch all non-links, sample.cc:249-293): the two uniform cases get their own straight-line copy of the
+        // step, with the per-column selects on y -- six v_cndmask per column pair and edge -- folded away
+        auto pair_step = [&](auto mode) {
+        asm volatile("" : "+v"(one));
         const float* row1 = ring + ((t + 1) % D) * KW;
         float sums[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // pi_a . pi_b and probs of edge t, of edge t + 1
         float lo0 = 1.0f, lo1 = 1.0f;
@@ -580,8 +618,8 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
           const f32x2 b0 = f32x2{row0[ln + 128 * p], row0[ln + 128 * p + 64]};
           const f32x2 b1 = f32x2{row1[ln + 128 * p], row1[ln + 128 * p + 64]};
           const f32x2 f0 = pa[p] * b0, f1 = pa[p] * b1;
-          pr0[p] = (y0 ? bk[p] : 1.0f - bk[p]) * f0;
-          pr1[p] = (y1 ? bk[p] : 1.0f - bk[p]) * f1;
+          pr0[p] = sel_b(p, y0, mode) * f0;
+          pr1[p] = sel_b(p, y1, mode) * f1;
           const float vx[4] = {f0.x, pr0[p].x, f1.x, pr1[p].x}, vy[4] = {f0.y, pr0[p].y, f1.y, pr1[p].y};
           VLn::template chain_rows<4>(sums, vx);
           VLn::template chain_rows<4>(sums, vy);
@@ -592,7 +630,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
         float tot[4];
         VLn::template tree_rows<4>(sums, tot);  // beta.cc:209-217, both edges
         BETA_TRACE(8 + 4 * (t / 2) + 3);
-        const float w0 = y0 ? EPS : (1.0f - EPS), w1 = y1 ? EPS : (1.0f - EPS);
+        const float w0 = sel_w(y0, mode), w1 = sel_w(y1, mode);
         const float ps0 = tot[1] + w0 * (1.0f - tot[0]), ps1 = tot[3] + w1 * (1.0f - tot[2]);
         // CALC_GRADS, beta.cc:161-171: edge t, then edge t + 1
         const bool fast0 = lo0 >= kProbsLo && in_range(ps0, kPsumLo, kPsumHi);
@@ -603,22 +641,25 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 #pragma unroll
           for (int p = 0; p < HP; ++p) {
             const f32x2 g0 = div_exact3(pr0[p], s0, q0), g1 = div_exact3(pr1[p], s1, q1);
-            acc0[p] += g0 * (y0 ? noo[p] : d0n[p]);
-            acc1[p] += g0 * (y0 ? d1l[p] : noo[p]);
-            acc0[p] += g1 * (y1 ? noo[p] : d0n[p]);
-            acc1[p] += g1 * (y1 ? d1l[p] : noo[p]);
+            acc0[p] += g0 * sel_0(p, y0, mode);
+            acc1[p] += g0 * sel_1(p, y0, mode);
+            acc0[p] += g1 * sel_0(p, y1, mode);
+            acc1[p] += g1 * sel_1(p, y1, mode);
           }
         } else {
 #pragma unroll
           for (int p = 0; p < HP; ++p) {
             const f32x2 g0 = f32x2{pr0[p].x / ps0, pr0[p].y / ps0};
-            acc0[p] += g0 * (y0 ? noo[p] : d0n[p]);
-            acc1[p] += g0 * (y0 ? d1l[p] : noo[p]);
+            acc0[p] += g0 * sel_0(p, y0, mode);
+            acc1[p] += g0 * sel_1(p, y0, mode);
             const f32x2 g1 = f32x2{pr1[p].x / ps1, pr1[p].y / ps1};
-            acc0[p] += g1 * (y1 ? noo[p] : d0n[p]);
-            acc1[p] += g1 * (y1 ? d1l[p] : noo[p]);
+            acc0[p] += g1 * sel_0(p, y1, mode);
+            acc1[p] += g1 * sel_1(p, y1, mode);
           }
         }
+        };
+        if (y0) pair_step(std::integral_constant<int, 2>{});
+        else pair_step(std::integral_constant<int, 1>{});
         t += 2;
       } else {
         float sums[2] = {0.0f, 0.0f};
@@ -727,6 +768,10 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       cur_u = u;
     }
 
+    // (the link flag is wave-uniform: each of its two values gets its own copy of the trip, without the per-column
+    // selects on y)
+    auto trip = [&](auto mode) {
+    asm volatile("" : "+v"(one));
     // CALC_PROBS, beta.cc:145-160
     // (probs[] stays in registers between the two passes: the write-back into the ring slot and its re-read cost a
     // wave ~15 % of a trip -- in-kernel stamps, tools/beta_trace.sh -- and 16 registers do not change the occupancy)
@@ -741,7 +786,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       if constexpr (FUSE) pb = pbn[p];
       else pb = f32x2{row_b[ln + 128 * p], row_b[ln + 128 * p + 64]};
       const f32x2 f = pa[p] * pb;
-      const f32x2 pr = (y ? bk[p] : 1.0f - bk[p]) * f;
+      const f32x2 pr = sel_b(p, y, mode) * f;
       prr[p] = pr;
       if constexpr (W == 1) {
         const float vx[2] = {f.x, pr.x}, vy[2] = {f.y, pr.y};
@@ -767,7 +812,7 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
       group_sum2(pi_sum, probs_sum);  // beta.cc:209-217
     }
     BETA_TRACE(8 + 4 * t + 3);
-    const float w = y ? EPS : (1.0f - EPS);
+    const float w = sel_w(y, mode);
     const float prob_0 = w * (1.0f - pi_sum);
     probs_sum += prob_0;
 
@@ -778,17 +823,20 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
         const f32x2 f = div_exact3(prr[p], psum2, rps2);
-        acc0[p] += f * (y ? noo[p] : d0n[p]);
-        acc1[p] += f * (y ? d1l[p] : noo[p]);
+        acc0[p] += f * sel_0(p, y, mode);
+        acc1[p] += f * sel_1(p, y, mode);
       }
     } else {
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
         const f32x2 f = f32x2{prr[p].x / probs_sum, prr[p].y / probs_sum};
-        acc0[p] += f * (y ? noo[p] : d0n[p]);
-        acc1[p] += f * (y ? d1l[p] : noo[p]);
+        acc0[p] += f * sel_0(p, y, mode);
+        acc1[p] += f * sel_1(p, y, mode);
       }
     }
+    };
+    if (y) trip(std::integral_constant<int, 2>{});
+    else trip(std::integral_constant<int, 1>{});
   }
 
   }
@@ -800,6 +848,25 @@ __global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a
     *reinterpret_cast<float2*>(out + 2 * (tid + 2 * L * p + L)) = make_float2(acc0[p].y, acc1[p].y);
   }
   BETA_BLK(1);
+}
+
+template <int KPT, int W, bool FUSE = false, int VL = 64>
+__global__ __launch_bounds__(64 * W) void beta_grads_lds_kernel(const BetaArgs a) {
+  beta_grads_lds_body<KPT, W, FUSE, VL>(a);
+}
+// K = 1024 on one wave per slot (the C3 shape): the launch is 2 048 slots = 8 waves per CU = two per SIMD, and it runs
+// beside the sampling chain of the mini-batch two steps ahead.  The register budget is said out loud (two waves per
+// SIMD); what matters beyond it is to stay well below 256: a build that used all of them (a third, run-time-selected
+// copy of the pair step kept every per-column constant alive) left a SIMD that also held one small wave of another
+// kernel room for only ONE of these waves, and the launch took a second round inside the loop (0.093 -> 0.118 ms)
+// while the same kernel launched alone did not change.  206 now.
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AMMSB_BETA_VGPRS))) void beta_grads_lds_kernel<16, 1, false, 64>(const BetaArgs a) {
+  beta_grads_lds_body<16, 1, false, 64>(a);
+}
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AMMSB_BETA_VGPRS))) void beta_grads_lds_kernel<16, 1, false, 32>(const BetaArgs a) {
+  beta_grads_lds_body<16, 1, false, 32>(a);
 }
 
 template <int KPT, int W, int VL = 64>

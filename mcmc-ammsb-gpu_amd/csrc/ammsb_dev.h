@@ -488,6 +488,43 @@ struct VLane {
     for (int r = 0; r < U; ++r)
       out[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), U == 4 ? 16 * r : 32 * r));
   }
+  // tree_rows plus the U reciprocals RN(1 / sum_r) from ONE IEEE division: after the last DPP level the sums sit in
+  // lanes 0, 16, 32, 48 of one register (U = 4; 0 and 32 for U = 2), so dividing that register once and reading the
+  // same lanes back gives each row exactly the quotient 1.0f / out[r] would -- a division costs ~11 vector
+  // instructions and the callers used to issue it once per row on a wave-uniform operand (44 of a four-row step's
+  // ~200 instructions at K = 256).  The other lanes divide by partial sums nobody reads.
+  template <int U>
+  __device__ __forceinline__ static void tree_rows_rcp(const float (&acc)[U], float (&out)[U], float (&rcp)[U]) {
+    static_assert(U == 2 || U == 4, "rows per step");
+    float h[U / 2];
+#pragma unroll
+    for (int r = 0; r < U / 2; ++r) {
+      if constexpr (VL == 64) {
+        const u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r]), __float_as_uint(acc[r + U / 2]), false, false);
+        h[r] = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+      } else {
+        h[r] = acc[r];
+      }
+    }
+    float v;
+    if constexpr (U == 4) {
+      const u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[0]), __float_as_uint(h[1]), false, false);
+      v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    } else {
+      const u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[0]), __float_as_uint(h[0]), false, false);
+      v = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    }
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, true));  // row_shl:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, true));  // row_shl:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, true));  // row_shl:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, true));  // row_shl:1
+    const float rv = 1.0f / v;  // (exact_rcp, every lane at once)
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+      out[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), U == 4 ? 16 * r : 32 * r));
+      rcp[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rv), U == 4 ? 16 * r : 32 * r));
+    }
+  }
   // stream / virtual lane of physical lane `tid`, and whether this lane keeps the virtual lane's draw number j
   // (VL = 64: the thread's own index within its node's group, which may span several waves)
   __device__ __forceinline__ static int vlane(int tid) { return VL == 64 ? tid : (tid & (VL - 1)); }

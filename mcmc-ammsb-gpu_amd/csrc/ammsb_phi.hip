@@ -897,7 +897,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT == 4 ? 4
         VLn::template chain_rows<U>(part, vx);  // all U rows' chains advance by the column pair (ammsb_dev.h)
         VLn::template chain_rows<U>(part, vy);
       }
-      VLn::template tree_rows<U>(part, psum);  // phi.cc:254-257
+      float prcp[U];
+      VLn::template tree_rows_rcp<U>(part, psum, prcp);  // phi.cc:254-257, and RN(1 / probs_sum) of all U rows in one division
 #pragma unroll
       for (int r = 0; r < U; ++r) {
         fast[r] = node_safe && lo[r] >= kProbsLo && in_range(psum[r], kPsumLo, kPsumHi);
@@ -910,9 +911,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT == 4 ? 4
         f32x2 s2[U], r2[U];
 #pragma unroll
         for (int r = 0; r < U; ++r) {
-          const float rc = exact_rcp(psum[r]);
           s2[r] = f32x2{psum[r], psum[r]};
-          r2[r] = f32x2{rc, rc};
+          r2[r] = f32x2{prcp[r], prcp[r]};
         }
 #pragma unroll
         for (int p = 0; p < HP; ++p) {
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPT == 4 ? 4
         for (int r = 0; r < U; ++r) {
           const float probs_sum = psum[r];
           if (fast[r]) {
-            const float rps = exact_rcp(probs_sum);
+            const float rps = prcp[r];
             float ps = phi_sum;
             asm volatile("" : "+v"(ps));
             const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};

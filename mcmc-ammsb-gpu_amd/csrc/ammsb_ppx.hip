@@ -192,7 +192,7 @@ typedef __attribute__((address_space(3))) void ppx_lds_void_t;
 typedef const __attribute__((address_space(1))) void ppx_glb_void_t;
 
 // VL = 32: the reference's default ppx_wg_size (main.cc:63) on the same one-wave-per-slot layout (VLane<32>).
-template <int KPT, uint32_t D, int VL = 64>
+template <int KPT, uint32_t D, int VL = 64, bool FOLD = false>
 __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
   using VLn = VLane<VL>;
   constexpr int K = 64 * KPT, HP = KPT / 2, PIECES = KPT / 4;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
     a.cnt_partials[2 * gs] = c_link;
     a.cnt_partials[2 * gs + 1] = c_non;
   }
-  if (!a.ticket) return;  // (launch-uniform) the two-launch form: ppx_reduce_kernel follows
+  if constexpr (FOLD) {
   // The launch adds up its own partials (cdna_hip_programming.md, split-K in-launch reduction / Guideline 16): partial
   // stores drained -> agent-scope release -> ticket; the block that draws the last ticket makes one agent-scope acquire
   // and reads every slot's partials with plain loads.  One wave per block: no barrier, the "I am last" word travels
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64) void ppx_lds_kernel(const PpxArgs a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring's last reads are done: its first 2 KiB are the scratch
   ppx_reduce_wave(a.ll_partials, a.cnt_partials, a.P, smem, a.out);
   if (l == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -479,13 +480,18 @@ int launch_ppx_lds(ammsb_ctx* ctx, const PpxArgs& a, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * sizeof(float) * 64 * KPT;
   static const std::string name = ammsb_kname("ppx_lds_kernel<%d, 2u, %d>", KPT, VL);
   ctx->kernel_name[AMMSB_KN_PPX] = name.c_str();
-  PpxArgs f = a;
-  f.ticket = ctx->ppx_ticket;  // this form reduces its own partials (no ppx_reduce_kernel launch)
-  static const bool two_launch = getenv("AMMSB_PPX_FOLD") && atoi(getenv("AMMSB_PPX_FOLD")) == 0;  // (A/B, tests)
-  if (two_launch) f.ticket = nullptr;
-  ppx_lds_kernel<KPT, 2, VL><<<a.P, 64, lds, s>>>(f);
+  // AMMSB_PPX_FOLD=1: the launch reduces its own partials (FOLD instantiation; no ppx_reduce_kernel launch)
+  static const bool fold = getenv("AMMSB_PPX_FOLD") && atoi(getenv("AMMSB_PPX_FOLD")) == 1;
+  if (fold) {
+    PpxArgs f = a;
+    f.ticket = ctx->ppx_ticket;
+    ppx_lds_kernel<KPT, 2, VL, true><<<a.P, 64, lds, s>>>(f);
+    AMMSB_LAUNCH_CHECK(ctx);
+    return 1;  // done, sums written
+  }
+  ppx_lds_kernel<KPT, 2, VL, false><<<a.P, 64, lds, s>>>(a);
   AMMSB_LAUNCH_CHECK(ctx);
-  return f.ticket ? 1 : AMMSB_OK;  // 1 = done, sums written
+  return AMMSB_OK;
 }
 
 // fixed-order reduction of the P per-slot partials: thread t adds slots t, t+256, ... ascending,

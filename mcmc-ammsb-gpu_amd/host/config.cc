@@ -52,6 +52,8 @@ Config::Config() {  // config.h:69-101
   device_sampling_host_seed = 20260101;
   sample_seed[0] = 1804289383u;
   sample_seed[1] = 846930886u;
+  phi_chunks = 4;
+  phi_replicate = -1;
 }
 
 std::ostream& operator<<(std::ostream& out, const ulong2& v) { return out << v[0] << "," << v[1]; }

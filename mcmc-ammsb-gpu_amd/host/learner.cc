@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <random>
 #include <sstream>
@@ -149,7 +150,17 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
     if (cfg_.graph_launch) throw std::runtime_error("graph_launch is single-rank (the exchange is not captured)");
     if (!ctx_) ctx_ = AcquireContext(cfg_, queue_);
     const uint32_t R = static_cast<uint32_t>(cfg_.exchange->world());
-    cc_ = (AMMSB_MAX_GROUPS + R - 1) / R;
+    SetSplit(cfg_.phi_replicate > 0 ? static_cast<uint32_t>(std::min<double>(cfg_.phi_replicate, 1.0) * AMMSB_MAX_GROUPS + 0.5) : 0u);
+    {
+      hipStream_t xs;
+      clcuda::Check(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking), "hipStreamCreate");
+      xstream_ = xs;
+      hipEvent_t a, b;
+      clcuda::Check(hipEventCreateWithFlags(&a, hipEventDisableTiming), "hipEventCreate");
+      clcuda::Check(hipEventCreateWithFlags(&b, hipEventDisableTiming), "hipEventCreate");
+      ev_block_ = a;
+      ev_xdone_ = b;
+    }
     const uint64_t max_nodes = samples_[0]->dev_nodes.Count();
     all_grads_.reset(new clcuda::Buffer<Float>(queue_.GetContext(), static_cast<uint64_t>(R) * 2 * cfg_.K));
     grads_sum_.reset(new clcuda::Buffer<Float>(queue_.GetContext(), 2 * cfg_.K));
@@ -162,6 +173,7 @@ Learner::Learner(const Config& cfg, clcuda::Queue queue)
   auto gamma = std::bind(gamma_distribution, mt19937);
   random::RandomAndNormalize(&queue_, gamma, &theta_, &beta_, 2);
   random::RandomGammaAndNormalize(&queue_, cfg_.eta0, cfg_.eta1, pi_.get(), &phi_);  // learner.cc:154-155
+  if (Sharded() && cfg_.phi_replicate < 0) CalibrateSplit();
   if (cfg_.graph_launch) {
     if (!cfg_.async_launch || !cfg_.device_sampling)
       throw std::runtime_error("graph_launch needs async_launch and device_sampling");
@@ -248,6 +260,12 @@ Learner::~Learner() {
       if (ev_consumed_[i]) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_consumed_[i]));
     }
     if (ev_sampler_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_sampler_));
+  }
+  if (xstream_) {
+    (void)hipDeviceSynchronize();
+    (void)hipStreamDestroy(static_cast<hipStream_t>(xstream_));
+    if (ev_block_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_block_));
+    if (ev_xdone_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_xdone_));
   }
 }
 
@@ -337,17 +355,93 @@ void Learner::Step(Sample& s, Float weight) {
   betaUpdater_(&s.dev_edges, s.num_edges, weight);
 }
 
-// One iteration over `world` ranks.  Ownership is fixed (rank r: groups [r cc, (r+1) cc)) because a group's RNG
-// streams advance only where the group runs; phi_vec row i < G belongs to group i, row G + t to group t (its second
-// node).  The in-place all-gather region is rows [0, world * cc), which can reach past G: owners park their tail rows
-// first and hand them out afterwards.  A launch whose groups all sit in rank 0's block (a link mini-batch of a
-// low-degree vertex) is a broadcast.  pi is bit-identical to a single rank's; theta differs by the association of the
-// gradient sum (per-rank partials summed in rank order).
+// Ownership map (as in mcmc-ammsb-gpu_amd/learner.py, _set_split): groups [0, g_rep) replicated, the rest in
+// world * nch blocks of cc groups; a rank's block of a chunk stays near or above one chip-load of one-wave nodes.
+void Learner::SetSplit(uint32_t g_rep) {
+  const uint32_t R = static_cast<uint32_t>(cfg_.exchange->world());
+  g_rep_ = std::min<uint32_t>(g_rep, AMMSB_MAX_GROUPS);
+  const uint32_t own = (AMMSB_MAX_GROUPS - g_rep_) / R;
+  nch_ = std::max<uint32_t>(1u, std::min<uint32_t>(std::max<uint32_t>(1u, cfg_.phi_chunks), own / 3072u));
+  const uint32_t blocks = R * nch_;
+  cc_ = std::max<uint32_t>(1u, (AMMSB_MAX_GROUPS - g_rep_ + blocks - 1) / blocks);
+}
+
+// Choose g_rep so that computing (replicated + own) groups takes as long as receiving the others' rows: T = one
+// update_phi over a full synthetic mini-batch, X = one all-gather of a full phi_vec; a fraction rho replicated costs
+// T (rho + (1 - rho) / R) of compute and X (1 - rho) of exchange.  The phi streams are restored, pi is not touched;
+// every rank adopts rank 0's answer.  (learner.py, _calibrate_split; the choice of exchange form stays with
+// AMMSB_EXCHANGE_FORM here.)
+void Learner::CalibrateSplit() {
+  Exchange& x = *cfg_.exchange;
+  const uint32_t R = static_cast<uint32_t>(x.world());
+  const uint32_t K = static_cast<uint32_t>(cfg_.K), nn = static_cast<uint32_t>(cfg_.num_node_sample);
+  hipStream_t stream = static_cast<hipStream_t>(queue_.stream());
+  Sample& s = *samples_[0];
+  const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(s.dev_nodes.Count(), AMMSB_MAX_GROUPS));
+  std::mt19937_64 gen(1);
+  std::vector<Vertex> nodes(n), nbrs(static_cast<size_t>(n) * nn);
+  for (Vertex& v : nodes) v = static_cast<Vertex>(gen() % cfg_.N);
+  for (Vertex& v : nbrs) v = static_cast<Vertex>(gen() % cfg_.N);
+  s.dev_nodes.Write(queue_, n, nodes.data());
+  s.neighbor_sampler.GetData().Write(queue_, nbrs.size(), nbrs.data());
+  std::vector<ammsb_seed> keep(phiUpdater_.Rand().GetSeeds().Count());
+  phiUpdater_.Rand().GetSeeds().Read(queue_, keep.size(), keep.data());
+  const uint32_t calls = phiUpdater_.CountCalls();
+  phiUpdater_.CountCalls() = 1;
+  auto timed = [&](const std::function<void()>& fn) {
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEvent_t a, b;
+      clcuda::Check(hipEventCreate(&a), "hipEventCreate");
+      clcuda::Check(hipEventCreate(&b), "hipEventCreate");
+      queue_.Finish();
+      x.Barrier();
+      clcuda::Check(hipEventRecord(a, stream), "hipEventRecord");
+      fn();
+      clcuda::Check(hipEventRecord(b, stream), "hipEventRecord");
+      clcuda::Check(hipEventSynchronize(b), "hipEventSynchronize");
+      float ms = 0;
+      clcuda::Check(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime");
+      best = std::min<double>(best, ms);
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+    }
+    return best;
+  };
+  const double T = timed([&] { phiUpdater_.UpdatePhi(s.dev_nodes, s.neighbor_sampler.GetData(), n, 0, 0xFFFFFFFFu); });
+  const uint32_t per = (n + R - 1) / R;
+  const double X = timed([&] { x.AllGatherInPlace(phiUpdater_.GetPhiVec().data(), static_cast<size_t>(per) * K * sizeof(Float), stream); }) *
+                   (static_cast<double>(n) / (static_cast<double>(per) * R));
+  phiUpdater_.Rand().GetSeeds().Write(queue_, keep.size(), keep.data());
+  phiUpdater_.CountCalls() = calls;
+  auto cost = [&](double r) { return std::max(T * (r + (1.0 - r) / R), X * (1.0 - r)); };
+  double rho = X > T / R ? (X - T / R) / (T - T / R + X) : 0.0;
+  rho = std::min(std::max(rho, 0.0), 1.0);
+  if (cost(1.0) <= cost(rho) * 1.02) rho = 1.0;  // links so slow that exchanging anything loses
+  x.BroadcastHost(&rho, sizeof rho, 0);           // one answer for the whole job: rank 0's
+  calib_phi_ms_ = T;
+  calib_xchg_ms_ = X;
+  SetSplit(static_cast<uint32_t>(rho * AMMSB_MAX_GROUPS));
+  queue_.Finish();
+  if (x.rank() == 0)
+    std::cerr << "I exchange split: update_phi " << T << " ms, full exchange " << X << " ms -> " << g_rep_ << " of "
+              << AMMSB_MAX_GROUPS << " groups replicated, " << nch_ << " chunk(s) of " << cc_ << " groups per rank"
+              << std::endl;
+}
+
+// One iteration over `world` ranks (the schedule of learner.py's _phi_sharded).  Ownership is fixed -- groups
+// [0, g_rep) run on every rank, block b of cc groups behind them on rank b % world -- because a group's RNG streams
+// advance only where the group runs; phi_vec row i < G belongs to group i, row G + t to group t (its second node).
+// Per chunk: update_phi over the own block on the main stream, then that chunk's in-place all-gather (region
+// [base, base + world * cc), which can reach past G: owners park their tail rows first and hand them out afterwards)
+// on the exchange stream, beside the next block and the replicated groups.  A chunk whose live groups all sit in rank
+// 0's block (a link mini-batch of a low-degree vertex) is a broadcast.  pi is bit-identical to a single rank's; theta
+// differs by the association of the gradient sum (per-rank partials summed in rank order).
 void Learner::StepSharded(Sample& s, Float weight) {
   Exchange& x = *cfg_.exchange;
-  const uint32_t R = static_cast<uint32_t>(x.world()), r = static_cast<uint32_t>(x.rank()), Cc = cc_;
+  const uint32_t R = static_cast<uint32_t>(x.world()), r = static_cast<uint32_t>(x.rank()), Cc = cc_, g0 = g_rep_;
   const uint32_t n = s.num_nodes, K = static_cast<uint32_t>(cfg_.K);
-  hipStream_t stream = static_cast<hipStream_t>(queue_.stream());
+  hipStream_t stream = static_cast<hipStream_t>(queue_.stream()), xs = static_cast<hipStream_t>(xstream_);
   clcuda::Buffer<Vertex>& nbrs = s.neighbor_sampler.GetData();
   Float* pv = phiUpdater_.GetPhiVec().data();
   Float* tb = tail_buf_->data();
@@ -355,21 +449,41 @@ void Learner::StepSharded(Sample& s, Float weight) {
   if (n == 0) throw std::runtime_error("mini-batch nodes size = 0!");  // phi.cc:732
   phiUpdater_.BeginCall();
   const uint32_t G = std::min<uint32_t>(n, AMMSB_MAX_GROUPS), tail = n - G;
-  const uint32_t lo = r * Cc, hi = std::min(lo + Cc, G);
-  if (lo < hi) phiUpdater_.UpdatePhi(s.dev_nodes, nbrs, n, lo, hi);
-  for (uint32_t b0 = 0; b0 < tail; b0 += Cc)
-    if ((b0 / Cc) % R == r)
-      clcuda::Check(hipMemcpyAsync(tb + static_cast<size_t>(b0) * K, pv + static_cast<size_t>(G + b0) * K,
-                                   (std::min(b0 + Cc, tail) - b0) * row, hipMemcpyDeviceToDevice, stream),
-                    "hipMemcpyAsync");
-  if (G <= Cc)
-    x.Broadcast(pv, G * row, 0, stream);
-  else
-    x.AllGatherInPlace(pv, Cc * row, stream);
-  if (tail > 0) {
-    for (uint32_t b0 = 0; b0 < tail; b0 += Cc)
-      x.Broadcast(tb + static_cast<size_t>(b0) * K, (std::min(b0 + Cc, tail) - b0) * row, static_cast<int>((b0 / Cc) % R), stream);
-    clcuda::Check(hipMemcpyAsync(pv + static_cast<size_t>(G) * K, tb, tail * row, hipMemcpyDeviceToDevice, stream),
+  const uint32_t rep_hi = std::min(g0, G), rep_tail = std::min(tail, rep_hi);
+  // replicated groups that own tail rows go first: the last all-gather region can reach past row G, and every sender
+  // must already hold the final value of whatever it sends from there
+  if (rep_tail > 0) phiUpdater_.UpdatePhi(s.dev_nodes, nbrs, n, 0, rep_tail);
+  bool exchanged = false;
+  if (G > g0) {
+    const uint32_t live = (G - g0 + R * Cc - 1) / (R * Cc);  // chunks with at least one live exchanged group
+    for (uint32_t c = 0; c < live; ++c) {
+      const uint32_t base = g0 + c * R * Cc, lo = base + r * Cc, hi = std::min(lo + Cc, G);
+      if (lo < hi) phiUpdater_.UpdatePhi(s.dev_nodes, nbrs, n, lo, hi);
+      if (c == live - 1 && tail > g0)  // exchanged groups with a tail row: owners park theirs before the region is overwritten
+        for (uint32_t b0 = g0; b0 < tail; b0 += Cc)
+          if (((b0 - g0) / Cc) % R == r)
+            clcuda::Check(hipMemcpyAsync(tb + static_cast<size_t>(b0) * K, pv + static_cast<size_t>(G + b0) * K,
+                                         (std::min(b0 + Cc, tail) - b0) * row, hipMemcpyDeviceToDevice, stream),
+                          "hipMemcpyAsync");
+      clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_block_), stream), "hipEventRecord");
+      clcuda::Check(hipStreamWaitEvent(xs, static_cast<hipEvent_t>(ev_block_), 0), "hipStreamWaitEvent");
+      if (G - base <= Cc)
+        x.Broadcast(pv + static_cast<size_t>(base) * K, (G - base) * row, 0, xs);
+      else
+        x.AllGatherInPlace(pv + static_cast<size_t>(base) * K, Cc * row, xs);
+      exchanged = true;
+    }
+  }
+  if (rep_hi > rep_tail) phiUpdater_.UpdatePhi(s.dev_nodes, nbrs, n, rep_tail, rep_hi);  // overlaps the exchanges in flight
+  if (exchanged) {
+    clcuda::Check(hipEventRecord(static_cast<hipEvent_t>(ev_xdone_), xs), "hipEventRecord");
+    clcuda::Check(hipStreamWaitEvent(stream, static_cast<hipEvent_t>(ev_xdone_), 0), "hipStreamWaitEvent");
+  }
+  if (tail > g0) {
+    for (uint32_t b0 = g0; b0 < tail; b0 += Cc)  // owners hand out their parked tail rows
+      x.Broadcast(tb + static_cast<size_t>(b0) * K, (std::min(b0 + Cc, tail) - b0) * row, static_cast<int>(((b0 - g0) / Cc) % R), stream);
+    clcuda::Check(hipMemcpyAsync(pv + static_cast<size_t>(G + g0) * K, tb + static_cast<size_t>(g0) * K, (tail - g0) * row,
+                                 hipMemcpyDeviceToDevice, stream),
                   "hipMemcpyAsync");
   }
   phiUpdater_.UpdatePi(s.dev_nodes, n);
@@ -418,10 +532,11 @@ void Learner::GatherShardedState() {
   queue_.Finish();
   const uint64_t L = phiUpdater_.Local(), count = phiUpdater_.Rand().GetSeeds().Count();
   ammsb_seed* seeds = phiUpdater_.Rand().Get();
-  for (uint32_t b = 0; b < R; ++b) {
-    const uint64_t lo = static_cast<uint64_t>(b) * cc_ * L, hi = std::min<uint64_t>(std::min<uint64_t>((b + 1ull) * cc_, AMMSB_MAX_GROUPS) * L, count);
+  for (uint32_t b = 0; b < R * nch_; ++b) {  // block b of cc_ groups behind the replicated prefix belongs to rank b % R
+    const uint64_t glo = static_cast<uint64_t>(g_rep_) + static_cast<uint64_t>(b) * cc_;
+    const uint64_t lo = glo * L, hi = std::min<uint64_t>(std::min<uint64_t>(glo + cc_, AMMSB_MAX_GROUPS) * L, count);
     if (lo >= hi) break;
-    x.Broadcast(seeds + lo, (hi - lo) * sizeof(ammsb_seed), static_cast<int>(b), queue_.stream());
+    x.Broadcast(seeds + lo, (hi - lo) * sizeof(ammsb_seed), static_cast<int>(b % R), queue_.stream());
   }
   std::vector<PerplexityCalculator*> calcs;
   if (trainingPerplexity_) calcs.push_back(trainingPerplexity_.get());

@@ -126,6 +126,8 @@ int main(int argc, char** argv) {
       Opt("async", 0, &cfg.async_launch, "0 (new: enqueue-only loop; needs --device-sampling 1)"),
       Opt("graph", 0, &cfg.graph_launch, "0 (new: iterations as captured hipGraphs; needs --async 1)"),
       Opt("loop-timers", 0, &cfg.loop_timers, "1 (new: per-kernel device times in PrintStats under --async / --graph)"),
+      Opt("phi-chunks", 0, &cfg.phi_chunks, "4 (new, with --exchange: blocks per rank whose exchange overlaps the next block's update_phi)"),
+      Opt("phi-replicate", 0, &cfg.phi_replicate, "-1 (new, with --exchange: fraction of the virtual groups every rank computes itself; < 0 = measured at start-up)"),
       OptStr("exchange", 0, &exchangeKind),  // (new) rccl | host: one process per GPU, RANK / WORLD_SIZE / MASTER_* from the env
       Opt("device", 0, &deviceId, "-1 (new: HIP device; default LOCAL_RANK with --exchange, else 0)"),
       OptStr("checkpoint-in", 0, &ckptIn),    // (new) Learner::Parse before the first iteration

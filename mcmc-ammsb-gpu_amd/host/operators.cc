@@ -36,7 +36,8 @@ uint64_t MaxNodes(const Config& cfg) {  // phi.cc:620-622
 uint64_t PhiVecRows(const Config& cfg) {
   uint64_t rows = MaxNodes(cfg);
   if (cfg.exchange && cfg.exchange->world() > 1)
-    rows = std::max<uint64_t>(rows, AMMSB_MAX_GROUPS + static_cast<uint64_t>(cfg.exchange->world()));
+    rows = std::max<uint64_t>(rows, AMMSB_MAX_GROUPS + static_cast<uint64_t>(cfg.exchange->world()) *
+                                                              std::max<uint32_t>(1u, cfg.phi_chunks));
   return rows;
 }
 uint64_t MaxEdges(const Config& cfg) {  // sample.cc:129
@@ -298,7 +299,9 @@ static const Config& CheckedPhiConfig(const Config& cfg) {
               << "(lane l owns columns l, l + wg, ...; one draw per column in ascending order).  The reference's width-"
               << cfg.phi_vector_width << " kernels give lane l the column vectors l, l + wg, ... of K / width and sum "
               << "a vector's components before the lane partial (phi.cc:214-275), which changes WG_SUM's association "
-              << "and the stream-to-column map" << std::endl;
+              << "and the stream-to-column map -- and draw a vector's noise as VLn(randn) = (Floatn)(randn, ..., randn) "
+              << "(types.cc:327-328), whose evaluation order OpenCL C leaves unspecified: the reference's own width-"
+              << cfg.phi_vector_width << " results are implementation-defined" << std::endl;
   if (cfg.sum_grads_vector_width != 1)
     std::cerr << "W sum_grads_vector_width " << cfg.sum_grads_vector_width << ": accepted; sum_grads' vector width only "
               << "widens its loads (beta.cc:39-49), the sums are the same" << std::endl;

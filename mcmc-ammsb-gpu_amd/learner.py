@@ -391,7 +391,80 @@ class Learner:
         self._set_split(int(float(t.item()) * MAX_GROUPS))
         ops.synchronize()
 
-    def _phi_sharded(self, s, n_nodes):
+    # ---- step trace of the multi-GPU schedule (bench.py's N > 1 record; None = off, the default).  A list here
+    # collects, for every iteration, timing marks on the main stream at the schedule's joints; shard_report() turns
+    # them into per-step phi / exchange / overlap / update_pi / gradient-exchange times once the device has caught up.
+    shard_trace = None
+
+    def _mark(self, rec, name, **kw):
+        if rec is not None:
+            rec["marks"].append((name, self.ops.timing_mark(), kw))
+
+    def shard_report(self):
+        """Means over the traced NON-LINK steps (a mini-batch of more than half the configured size), in ms: what the
+        first multi-GPU run needs to be read -- where a step's time went next to what the calibration predicted."""
+        ops, tr = self.ops, self.shard_trace or []
+        ops.synchronize()
+        big = [r for r in tr if r["n_nodes"] > self.cfg.mini_batch_size // 2]
+        if not big:
+            return {"steps": 0}
+        K = self.cfg.K
+        acc, chunks = {}, {}
+
+        def add(k, v):
+            acc.setdefault(k, []).append(v)
+        for r in big:
+            m = r["marks"]
+            t = {name: ev for name, ev, _ in m if not name.startswith(("phi_done", "xchg_done"))}
+            el = lambda a, b: ops.mark_elapsed_ms(t[a], t[b])  # noqa: E731
+            add("step_ms", el("begin", "end"))
+            add("phi_phase_ms", el("begin", "phi_end"))
+            add("update_pi_ms", el("phi_end", "pi_end"))
+            add("grads_local_ms", el("pi_end", "grads_local"))
+            add("grad_allgather_ms", el("grads_local", "grads_reduced"))
+            add("update_theta_ms", el("grads_reduced", "end"))
+            # own blocks: launched back to back on the main stream; the exchange of chunk c cannot start before its
+            # block is computed and is known to be over when the main stream's wait for it returns
+            pd = [(kw["chunk"], ev) for name, ev, kw in m if name.startswith("phi_done")]
+            xd = [(kw["chunk"], ev, kw["bytes"]) for name, ev, kw in m if name.startswith("xchg_done")]
+            if pd:
+                add("phi_local_ms", ops.mark_elapsed_ms(t["begin"], pd[-1][1]))
+            if "rep_done" in t:
+                add("phi_replicated_ms", ops.mark_elapsed_ms(pd[-1][1] if pd else t["begin"], t["rep_done"]))
+            exposed_from = t.get("rep_done", pd[-1][1] if pd else t["begin"])
+            if xd:
+                add("exchange_exposed_ms", max(0.0, ops.mark_elapsed_ms(exposed_from, xd[-1][1])))
+                prev = None
+                for (c, ev, nbytes) in xd:
+                    start = dict(pd).get(c, t["begin"])
+                    d0 = ops.mark_elapsed_ms(start, ev)
+                    if prev is not None:
+                        d0 = min(d0, ops.mark_elapsed_ms(prev, ev))
+                    d0 = max(d0, 1e-6)
+                    chunks.setdefault(c, {"ms": [], "bytes": nbytes})["ms"].append(d0)
+                    prev = ev
+        out = {k: float(np.mean(v)) for k, v in acc.items()}
+        out["steps"] = len(big)
+        per_chunk = []
+        tot_ms = 0.0
+        for c in sorted(chunks):
+            ms = float(np.mean(chunks[c]["ms"]))
+            tot_ms += ms
+            per_chunk.append({"chunk": c, "exchange_ms": ms, "received_bytes": int(chunks[c]["bytes"]),
+                              "GBps": chunks[c]["bytes"] / (ms * 1e-3) / 1e9})
+        out["exchange_chunks"] = per_chunk
+        out["exchange_ms"] = tot_ms
+        if per_chunk:
+            out["allgather_GBps_received"] = sum(c["received_bytes"] for c in per_chunk) / (tot_ms * 1e-3) / 1e9
+            out["overlap_ms"] = max(0.0, tot_ms - out.get("exchange_exposed_ms", 0.0))
+        out["how"] = ("timing marks on the main stream at the joints of the sharded step (after each own block's launch, "
+                      "after the wait for each chunk's exchange, after the replicated groups, update_pi, the local "
+                      "gradient, its rank-ordered reduction, the theta step); exchange_ms of a chunk = from its block's "
+                      "end (or the previous chunk's exchange) to the end of its wait: an upper bound; overlap_ms = "
+                      "exchange_ms - what was still exposed after the last compute of the phase")
+        return out
+
+    def _phi_sharded(self, s, n_nodes, rec=None):
         """update_phi over this rank's groups with the phi_vec exchange overlapped: own block of chunk 0,
         all-gather it (async), own block of chunk 1, ..., then the replicated groups while the last
         exchanges are still in flight."""
@@ -429,23 +502,29 @@ class Learner:
                 hi = min(lo + Cc, G)
                 if lo < hi:
                     phi.update_phi(nodes, nbrs, n_nodes, lo, hi)
+                self._mark(rec, "phi_done%d" % c, chunk=c)
                 if c == live_chunks - 1 and tail > g0:
                     # exchanged groups with a tail row: park each owner's rows before the region is overwritten
                     for b0 in range(g0, tail, Cc):
                         if ((b0 - g0) // Cc) % R == r:
                             b1 = min(b0 + Cc, tail)
                             self.tail_buf[b0:b1].copy_(pv[G + b0:G + b1])
+                row_bytes = 4 * pv.shape[1]
                 if G - base <= Cc:  # only rank 0's block is live in this chunk: a broadcast is enough
-                    works.append(ops.broadcast_async(dist, pv[base:G], 0, self.group))
+                    works.append((c, (G - base) * row_bytes if r != 0 else 0, ops.broadcast_async(dist, pv[base:G], 0, self.group)))
                 else:
-                    works.append(ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group,
-                                                           mode="p2p" if self.xchg_mode == "p2p" else "collective"))
+                    works.append((c, (R - 1) * Cc * row_bytes,
+                                  ops.all_gather_rows_async(dist, pv[base:base + R * Cc], Cc, r, R, self.group,
+                                                            mode="p2p" if self.xchg_mode == "p2p" else "collective")))
         if rep_hi > rep_tail and not forked:
             phi.update_phi(nodes, nbrs, n_nodes, rep_tail, rep_hi)  # overlaps the exchanges in flight
-        for w in works:
+            self._mark(rec, "rep_done")
+        for c, nbytes, w in works:
             ops.wait_work(w)
+            self._mark(rec, "xchg_done%d" % c, chunk=c, bytes=nbytes)
         if forked:
             ops.wait_event(self.ev_join)
+            self._mark(rec, "rep_joined")  # (side stream: the join comes after the exchange waits, it is not a compute joint)
         if tail > g0:
             for b0 in range(g0, tail, Cc):  # owners hand out their parked tail rows
                 b1 = min(b0 + Cc, tail)
@@ -561,15 +640,26 @@ class Learner:
             phi.count_calls += 1
             if n_nodes == 0:
                 raise AmmsbError("mini-batch nodes size = 0!")
-            self._phi_sharded(s, n_nodes)
+            rec = None
+            if self.shard_trace is not None and self.sharded:
+                rec = {"n_nodes": n_nodes, "n_edges": n_edges, "marks": []}
+                self.shard_trace.append(rec)
+            self._mark(rec, "begin")
+            self._phi_sharded(s, n_nodes, rec)
+            self._mark(rec, "phi_end")
             phi.update_pi(s.dev_nodes, n_nodes)
+            self._mark(rec, "pi_end")
 
             # betaUpdater_(edges, n, weight)  -- beta.cc:334-384
             beta = self.betaUpdater
             beta.count_calls += 1
             e_lo, e_hi = self._edge_range(n_edges)
             local = beta.calculate_grads(s.dev_edges, n_edges, e_lo, e_hi)
-            beta.update_theta(weight, self._reduce_grads(local))
+            self._mark(rec, "grads_local")
+            total = self._reduce_grads(local)
+            self._mark(rec, "grads_reduced")
+            beta.update_theta(weight, total)
+            self._mark(rec, "end")
 
             ops.record_event(s.consumed)
             s.consumed_valid = True

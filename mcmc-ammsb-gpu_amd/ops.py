@@ -775,6 +775,18 @@ def synchronize():
     torch.cuda.synchronize()
 
 
+def timing_mark():
+    """A timing event recorded on torch's current stream (the multi-GPU step trace, Learner.shard_trace)."""
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def mark_elapsed_ms(a, b):
+    """Device time between two timing_mark()s (both must have completed: call synchronize() first)."""
+    return a.elapsed_time(b)
+
+
 def elapsed_ms(fn):
     """Device time of fn() on the current stream (HIP events), for start-up calibration."""
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

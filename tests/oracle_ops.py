@@ -267,6 +267,15 @@ def synchronize():
     pass
 
 
+def timing_mark():
+    import time
+    return time.perf_counter()
+
+
+def mark_elapsed_ms(a, b):
+    return (b - a) * 1e3
+
+
 def pinned(shape, dtype):
     return torch.zeros(shape, dtype=dtype)
 

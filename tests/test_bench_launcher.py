@@ -79,3 +79,11 @@ def test_plain_bench_two_ranks_end_to_end():
     assert split is not None and split["exchange"] in ("collective", "p2p") and 0.0 <= split["rho"] <= 1.0
     assert split["predicted_phi_speedup"] is None or split["predicted_phi_speedup"] > 0
     assert rec["config"]["parallelism"].endswith("x2")
+    # the step trace that makes a multi-GPU line diagnosable by itself
+    tr = split["trace"]
+    assert "error" not in tr, tr
+    if tr["steps"]:
+        for key in ("step_ms", "phi_phase_ms", "update_pi_ms", "grads_local_ms", "grad_allgather_ms", "update_theta_ms",
+                    "exchange_ms", "exchange_chunks"):
+            assert key in tr, key
+        assert tr["step_ms"] > 0

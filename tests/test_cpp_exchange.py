@@ -208,12 +208,13 @@ def _dataset(tmp_path, N, deg, flags, seed):
     return d
 
 
-def _run_case(tmp_path, d, world, flags, iters, interval, ppx_rtol, tag, timeout=900):
+def _run_case(tmp_path, d, world, flags, iters, interval, ppx_rtol, tag, timeout=900, split=("--phi-replicate", "0", "--phi-chunks", "1")):
+    # (`split`: the ranks' sharding flags -- default: every group exchanged in one chunk, the plain schedule)
     common = [EXE, "--load-data", "1", "--load-file", d] + flags + ["-x", str(iters), "-i", str(interval)]
     ck1 = str(tmp_path / (tag + "single.ckpt"))
     one = subprocess.run(common + ["--checkpoint-out", ck1], capture_output=True, text=True, timeout=timeout)
     assert one.returncode == 0, one.stderr
-    res = _ranks(common + ["--exchange", "host"], world, timeout=timeout,
+    res = _ranks(common + ["--exchange", "host"] + list(split), world, timeout=timeout,
                  per_rank_args=lambda r: ["--checkpoint-out", str(tmp_path / ("%srank%d.ckpt" % (tag, r)))])
     ppx1 = _ppx_lines(one.stderr)
     assert len(ppx1) == iters // interval + 1
@@ -252,3 +253,23 @@ def test_three_ranks_full_blocks_and_tail_rows(built, tmp_path):
     d = _dataset(tmp_path, 150000, 10, flags, seed=11)
     _compare(*_run_case(tmp_path, d, 3, flags + ["-s", "NodeNonLink"], iters=1, interval=1, ppx_rtol=1e-5, tag="a"), K, _heldout_edges(d))
     _run_case(tmp_path, d, 3, flags + ["-s", "Node"], iters=8, interval=4, ppx_rtol=3e-3, tag="b")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split,tag", [
+    (("--phi-replicate", "0.3", "--phi-chunks", "2"), "hybrid"),      # 30 % of the groups replicated, two overlapped chunks per rank
+    (("--phi-replicate", "0.00003", "--phi-chunks", "3"), "mixed"),   # ONE replicated group: replicated and exchanged tail rows
+    (("--phi-replicate", "-1"), "auto"),                              # measured at start-up (whatever it comes out as)
+])
+def test_hybrid_split_and_chunked_exchange(built, tmp_path, split, tag):
+    """The tuned schedule of learner.py behind the C++ API (Config::phi_replicate / phi_chunks): replicated prefix,
+    world * chunks blocks exchanged on their own stream beside the next block's update_phi, tail rows of both kinds.
+    One iteration: pi, phi_sum, every RNG stream and the pending samples byte-identical to a single rank's; the
+    checkpoint (a collective) carries the owners' streams whatever the split."""
+    K = 32
+    flags = ["-k", str(K), "-m", "65536", "-n", "32", "-r", "0.02", "--phi-wg", "32", "--beta-wg", "32", "--ppx-wg", "32",
+             "--device-sampling", "1", "--async", "1"]
+    d = _dataset(tmp_path, 150000, 10, flags, seed=11)
+    _compare(*_run_case(tmp_path, d, 3, flags + ["-s", "NodeNonLink"], iters=1, interval=1, ppx_rtol=1e-5, tag=tag + "a",
+                        split=split), K, _heldout_edges(d))
+    _run_case(tmp_path, d, 2, flags + ["-s", "Node"], iters=6, interval=3, ppx_rtol=3e-3, tag=tag + "b", split=split)

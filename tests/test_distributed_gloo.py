@@ -45,11 +45,18 @@ def _run(rank, world, port, outdir, case, chunks=4, rep="auto"):
                                            phi_replicate=rep)
     lrn = learner.Learner(cfg, ds, ops=oracle_ops, rank=rank, world_size=world, group=group)
     p0 = lrn.HeldoutPerplexity()
+    if world > 1:
+        lrn.shard_trace = []  # the step trace bench.py's N > 1 record is made of (marks only: the trajectory is untouched)
     lrn.Run(1)
     pi1 = lrn.pi.host()
     lrn.Run(iters - 1)
     p1 = lrn.HeldoutPerplexity()
     lrn.drain()
+    if world > 1:
+        import json
+        rep_ = lrn.shard_report()
+        with open(os.path.join(outdir, "w%d_r%d_trace.json" % (world, rank)), "w") as f:
+            json.dump({"report": rep_, "steps_traced": len(lrn.shard_trace)}, f)
     np.savez(os.path.join(outdir, "w%d_r%d.npz" % (world, rank)), pi1=pi1, pi=lrn.pi.host(), phi=lrn.phi.numpy(),
              theta=lrn.theta.numpy(), beta=lrn.beta.numpy(), ppx=np.array([p0, p1]), edges=np.array([lrn.edges_done]),
              seeds=lrn.phiUpdater.rand.host().view(np.uint64), ppx_state=lrn.heldoutPerplexity.ppx_per_edge.numpy(),
@@ -88,6 +95,22 @@ def test_world2_matches_single_process(tmp_path, case, chunks, rep):
     # replicas stay identical
     for k in ("pi", "phi", "theta", "beta", "ppx", "edges"):
         assert np.array_equal(r0[k], r1[k]), k
+    # the step trace (what makes the first multi-GPU bench line diagnosable): every joint of the sharded step is there
+    import json
+    for r in range(2):
+        tr = json.load(open(os.path.join(out, "w2_r%d_trace.json" % r)))
+        assert tr["steps_traced"] == case[4]
+        rp = tr["report"]
+        if rp["steps"]:  # (non-link steps of the run)
+            for key in ("step_ms", "phi_phase_ms", "update_pi_ms", "grads_local_ms", "grad_allgather_ms", "update_theta_ms",
+                        "exchange_ms", "exchange_chunks", "how"):
+                assert key in rp, key
+            assert rp["step_ms"] > 0 and rp["phi_phase_ms"] <= rp["step_ms"] * 1.001
+            parts = rp["phi_phase_ms"] + rp["update_pi_ms"] + rp["grads_local_ms"] + rp["grad_allgather_ms"] + rp["update_theta_ms"]
+            assert abs(parts - rp["step_ms"]) <= 1e-6 * max(1.0, rp["step_ms"]) + 1e-3
+            if rp["exchange_chunks"]:
+                assert all(c["exchange_ms"] > 0 and c["received_bytes"] >= 0 for c in rp["exchange_chunks"])
+                assert "overlap_ms" in rp and "allgather_GBps_received" in rp and "phi_local_ms" in rp
     # first iteration: phi/pi do not depend on how groups are split over ranks -> bit-identical to 1 process
     assert np.array_equal(r0["pi1"], one["pi1"])
     assert r0["edges"][0] == one["edges"][0]
