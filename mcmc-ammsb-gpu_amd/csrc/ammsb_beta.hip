@@ -1351,10 +1351,12 @@ static bool beta_fuse_shape(ammsb_ctx* ctx, uint32_t wg) {
     const char* g = getenv("AMMSB_LOOP_FUSE_PI");
     return (f && (f[0] == 'r' || f[0] == 'g')) || (g && atoi(g) == 0);
   }();
-  // K = 1024 is built and tested too (AMMSB_LOOP_FUSE_PI=2) but not taken by default: at C3 the step time does not
-  // change (the gradient kernel is latency-bound per wave and the normalisation lands on its critical path), while the
-  // shorter main chain moves more of the concurrent sampling chain under update_phi
-  static const bool k1024 = getenv("AMMSB_LOOP_FUSE_PI") && atoi(getenv("AMMSB_LOOP_FUSE_PI")) == 2;
+  // K = 1024 too since round 4 (AMMSB_LOOP_FUSE_PI=1 keeps it to K <= 512, the earlier default): with the gradient
+  // constants from the per-theta table and the per-flag copies of the trip, the fused launch takes 0.111-0.114 ms at C3
+  // against 0.084 (update_pi) + 0.089 (gradient) separately -- one launch and one pass over 268 MB of rows less; the
+  // non-link step 1.905 -> 1.86-1.875 ms although update_phi's stamped time grows by 0.02 ms (the shorter main chain
+  // moves more of the concurrent sampling chain under it); same-box alternation, gpurun_out/r04/call10.log.
+  static const bool k1024 = !(getenv("AMMSB_LOOP_FUSE_PI") && atoi(getenv("AMMSB_LOOP_FUSE_PI")) == 1);
   if (off) return false;
   if ((wg == 64 || wg == 32) && (K == 256 || K == 512 || (K == 1024 && k1024))) return true;  // beta_grads_lds_kernel<KPT, 1, true, wg>
   return (wg == 32 || wg == 64) && K <= 2 * wg;                                   // beta_grads_kernel<L, 1 | 2, true>

@@ -87,3 +87,25 @@ def test_plain_bench_two_ranks_end_to_end():
                     "exchange_ms", "exchange_chunks"):
             assert key in tr, key
         assert tr["step_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_device_state_and_settle():
+    """One JSON line; `roofline.device_state` says what the line ran at (sysfs clocks / power before and after the timed
+    window, partitions, the shader clock held under load per XCD) and `settle` what ran before the warm-up steps."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, BENCH, "--workload", "C1", "--steps", "200", "--warmup", "20", "--settle-s", "0.2",
+                          "--no-cpu-baseline", "--cpp-dropin", "0", "--extras", "0"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 200 and rec["value"] > 0 and rec["dtype"] == "f32"
+    assert rec["settle"]["steps"] > 0 and rec["settle"]["seconds"] == 0.2
+    ds = rec["roofline"]["device_state"]
+    assert ds["compute_partition"] and ds["memory_partition"]
+    assert len(ds["sclk_mhz"]) == 2 and len(ds["power_w"]) == 2 and ds["power_cap_w"][0] > 0
+    assert 300 < ds["shader_clock_under_load_mhz"] < 2600 and len(ds["shader_clock_per_xcd_mhz"]) == 8
+    assert rec["large_configs"] is None and rec["small_configs"] is None  # (--extras 0)

@@ -105,9 +105,11 @@ def test_loop_launch_forms_agree(env, small_ds, monkeypatch):
         assert ppx == ref_ppx, form
 
 
-def test_fused_update_pi_at_k1024(env, small_ds, monkeypatch):
-    """The K = 1024 instantiation of the gradient kernel with update_pi folded in is opt-in (AMMSB_LOOP_FUSE_PI=2; the
-    flag is read once per process, so this runs in a child): the loop still equals the eager loop bit for bit."""
+@pytest.mark.parametrize("fuse,wg", [("", 64), ("", 32), ("1", 64), ("0", 64)])
+def test_fused_update_pi_at_k1024(env, small_ds, monkeypatch, fuse, wg):
+    """K = 1024 in the loop: by default update_pi is folded into the gradient kernel (since round 4; AMMSB_LOOP_FUSE_PI=1
+    keeps the fusion to K <= 512, =0 turns it off; the flag is read once per process, so each setting runs in a child):
+    the loop equals the eager loop bit for bit in every setting, at wg 64 and at the reference's default wg 32."""
     import os
     import subprocess
     import sys
@@ -116,19 +118,23 @@ def test_fused_update_pi_at_k1024(env, small_ds, monkeypatch):
         "from mcmc_ammsb_gpu_amd import hostlib, learner, ops\n"
         "ds = hostlib.Dataset.robust(20000, hostlib.generate_graph(20000, 16, 16, seed=7), heldout_ratio=0.02, rand_seed=3)\n"
         "def make(g):\n"
-        "    cfg = learner.Config.from_cli_defaults(K=1024, mini_batch_size=200, num_node_sample=16, strategy='Node', phi_wg_size=64,\n"
-        "                                           beta_wg_size=64, ppx_wg_size=64, device_sampling=True, graph_launch=g)\n"
+        "    cfg = learner.Config.from_cli_defaults(K=1024, mini_batch_size=200, num_node_sample=16, strategy='Node', phi_wg_size=%d,\n"
+        "                                           beta_wg_size=%d, ppx_wg_size=%d, device_sampling=True, graph_launch=g)\n" % (wg, wg, wg) +
         "    return learner.Learner(cfg, ds)\n"
         "a, b = make(False), make(True)\n"
         "for n in (1, 2, 37):\n"
         "    a.Run(n); b.Run(n); a.drain(); b.drain()\n"
         "    assert np.array_equal(a.pi.host(), b.pi.host()) and np.array_equal(ops.to_numpy(a.theta), ops.to_numpy(b.theta))\n"
         "    assert np.array_equal(ops.to_numpy(a.phi), ops.to_numpy(b.phi))\n"
-        "print('OK')\n")
+        "print('OK', b.ctx.kernel_names()['beta_grads'])\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, AMMSB_LOOP_FUSE_PI="2"),
-                       capture_output=True, text=True, timeout=600)
+    child_env = {k: v for k, v in os.environ.items() if k != "AMMSB_LOOP_FUSE_PI"}
+    if fuse:
+        child_env["AMMSB_LOOP_FUSE_PI"] = fuse
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=child_env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    # the kernel the loop's last gradient launch took: fused (third template argument true) exactly when asked for
+    assert ("beta_grads_lds_kernel<16, 1, true, %d>" % wg in r.stdout) == (fuse == ""), r.stdout
 
 
 def test_graph_and_eager_steps_interleave(env, small_ds):

@@ -29,7 +29,7 @@ import oracle_lib as orc
 orc.build()
 from test_gpu_parity import Problem
 K, ne = [int(x) for x in sys.argv[1:3]]
-N = max(2 * ne, 20000)
+N = int(os.environ.get("BETA_TRACE_N", max(2 * ne, 20000)))
 pr = Problem(orc, hip, N, K, 8, 16, deg=8)
 rng = np.random.default_rng(1)
 u = int(rng.integers(0, N))
