@@ -174,7 +174,9 @@ int ammsb_beta_from_theta(ammsb_ctx* ctx, const float* theta, float* beta, void*
 
 /* PerplexityCalculator::operator(), perplexity.cc:251-274, kernel :159-181 + the four reductions
  * (:318-331).  Edges [edge_begin, edge_end) of the held-out list; ppx_per_edge is the running-mean
- * state (indexed by global edge position); call_count is 1-based.  out: device ammsb_ppx_sums. */
+ * state (indexed by global edge position); call_count is 1-based.  out: an ammsb_ppx_sums in device memory, or in
+ * host-mapped pinned memory (hipHostMalloc) -- the 32 bytes are then on the host once the stream has been
+ * synchronised, without a copy (what both hosts of this repository do for the unsharded call). */
 int ammsb_perplexity(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const ammsb_set* heldout_set,
                      const uint64_t* edges, uint32_t n_edges, uint32_t edge_begin, uint32_t edge_end,
                      uint32_t call_count, uint32_t wg, float* ppx_per_edge, ammsb_ppx_sums* out, void* stream);
