@@ -50,6 +50,10 @@ extern "C" int ammsb_debug_blocks(unsigned long long* out, int n_blocks) {
 #define PHI_BLK(end) do { } while (0)
 #endif
 
+#ifndef AMMSB_PHI_LDS3_DEFAULT
+#define AMMSB_PHI_LDS3_DEFAULT false
+#endif
+
 namespace {
 
 struct PhiArgs {
@@ -683,6 +687,217 @@ __global__ __launch_bounds__(64 * W * NB) __attribute__((amdgpu_waves_per_eu(KPT
     }
   }
   if (a.noise_on && tid < LV) a.seeds[(uint64_t)g * LV + tid] = rs;
+  PHI_BLK(1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K = 1024 (KPT = 16), one wave per node, THREE ring slots in the LDS of two slots + the noise buffer (round 4).
+//
+// update_phi_lds_kernel<16, 1, 2> keeps per wave two 4 KiB ring slots and a 4 KiB buffer of sqrt(eps_t phi_k) * normal_k:
+// eleven one-wave blocks per CU (LDS), ONE row in flight per wave while another is reduced -- 44 KB in flight per CU
+// against a loaded HBM latency of ~2 us, and SQ counters that show the waves parked on s_waitcnt 58 % of their life.
+// A third slot at the same LDS footprint needs the noise buffer gone.  Here the lane's normals go where the node's
+// output row will go: draw j is stored (raw) to phi_vec[i][ln + 64 j], and after the last neighbour row the ring fetches
+// that 4 KiB row back like one more row -- it has exactly a pi row's layout -- so the noise costs no LDS, no registers,
+// and its latency is covered like a row's.  sqrt(eps_t phi_k) is evaluated in the SGLD step instead of the prologue and
+// multiplied with the normal there: the same product (a * b == b * a), bit-identical results, same stream order.
+// Two rows in flight per wave at eleven waves per CU.  Needs n >= KV + 2 (the loop draws one normal per row, the noise
+// row is requested two rows before the end); the launcher falls back to the two-slot kernel otherwise.
+template <int KPT, int VL = 64, bool ONE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void update_phi_lds3_kernel(const PhiArgs a) {
+  if constexpr (ONE) __builtin_assume(a.pi.num_blocks == 1);
+  using VLn = VLane<VL>;
+  constexpr int D = 3;
+  constexpr int KV = KPT * VLn::PER;  // normals per virtual lane
+  constexpr int L = 64, KW = 64 * KPT, K = L * KPT, PIECES = KPT / 4, HP = KPT / 2;
+  extern __shared__ __align__(16) char smem[];  // [D][KW] ring, then [n] u32 (id | link bit)
+  __shared__ ZigTables zig;
+  const int tid = threadIdx.x, ln = tid;
+  const uint32_t n = a.n;
+  float* ring = reinterpret_cast<float*>(smem);
+  uint32_t* s_nb = reinterpret_cast<uint32_t*>(smem + D * KW * sizeof(float));
+
+  const PhiStep st = phi_step(a);
+  note_stamp(a.stamps, a.desc, AMMSB_STAMP_PHI);
+  const uint32_t g = a.group_begin + blockIdx.x;
+  if (g >= st.group_end) return;  // block-uniform
+  PHI_BLK(0);
+  const float EPS = a.epsilon;
+  if (a.noise_on) zig_load(&zig);
+
+  f32x2 bf[HP];
+  bool beta_safe = true;
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    const float b0 = a.beta[2 * (tid + 2 * L * p) + 1];
+    const float b1 = a.beta[2 * (tid + 2 * L * p + L) + 1];
+    bf[p] = f32x2{b0 - EPS, b1 - EPS};
+    beta_safe = beta_safe && in_range(b0, EPS, kBetaHi) && in_range(b1, EPS, kBetaHi);
+  }
+  ammsb_seed rs = {0, 0};
+  if (a.noise_on) rs = a.seeds[(uint64_t)g * VL + VLn::vlane(tid)];
+
+  // 4 KiB at `src_row` into ring slot `slot`: piece t carries chunks j = 4t .. 4t+3 (16 lanes x 16 B each), so the row
+  // lands as [j][64] and lane ln reads column ln + 64 j at [j * 64 + ln]
+  auto fetch = [&](const float* src_row, uint32_t slot, bool nt) {
+    const float* src = src_row + 4 * tid;
+    char* dst = smem + slot * (KW * sizeof(float));
+    if (nt) {
+#pragma unroll
+      for (int t = 0; t < PIECES; ++t)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 2);
+    } else {
+#pragma unroll
+      for (int t = 0; t < PIECES; ++t)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 4 * L * t), (lds_void_t*)(dst + 1024 * t), 16, 0, 0);
+    }
+  };
+
+  for (uint64_t i = g; i < st.n_nodes; i += st.G) {
+    const uint32_t node = a.nodes[i];
+    float* out = a.phi_vec + i * K;
+    __syncthreads();  // orders the LDS traffic of consecutive nodes
+    for (uint32_t q = tid; q < n; q += L) {
+      const uint32_t nbq = a.neighbors[i * n + q];
+      const bool y = set_has(a.set, make_edge(node, nbq));
+      s_nb[q] = nbq | (y ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+    // row r of the node's stream: neighbour r for r < n, the node's noise row (its output row, holding the raw normals
+    // the loop has stored there) for r == n
+    auto request = [&](uint32_t r, uint32_t slot) {
+      if (r < n) {
+        const uint32_t nbr = __builtin_amdgcn_readfirstlane(s_nb[r] & 0x7fffffffu);
+        fetch(rpm_row(a.pi, nbr), slot, a.rows_nt != 0);
+      } else {
+        // (the row's address is loop-invariant: computed here, behind an empty asm, and not hoisted into four more
+        // 64-bit address registers that live across the row loop -- the kernel sits exactly at its register budget, and
+        // a spilled address is reloaded by a scratch load whose wait drains the ring every trip)
+        const float* o = out;
+        asm volatile("" : "+s"(o));
+        fetch(o, slot, false);
+      }
+    };
+
+    const float phi_sum = a.phi_sum[node];
+    const float inv_phi_sum = 1.0f / phi_sum;
+    const float* row_a = rpm_row(a.pi, node);
+    f32x2 pi_a[HP], grads[HP], rden[HP];
+    bool node_safe = beta_safe && in_range(phi_sum, kPhiSumLo, kPhiSumHi);
+#pragma unroll
+    for (int p = 0; p < HP; ++p)
+      pi_a[p] = f32x2{__builtin_nontemporal_load(row_a + tid + 2 * L * p), __builtin_nontemporal_load(row_a + tid + 2 * L * p + L)};
+    request(0, 0);  // (n >= 2 here)
+    request(1, 1);
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      grads[p] = f32x2{0.0f, 0.0f};
+      const f32x2 den = pi_a[p] * phi_sum;
+      rden[p] = f32x2{exact_rcp(den.x), exact_rcp(den.y)};
+      node_safe = node_safe && in_range(den.x, kDenLo, kDenHi) && in_range(den.y, kDenLo, kDenHi);
+    }
+
+    uint32_t slot = 0;  // q % 3
+    for (uint32_t q = 0; q < n; ++q) {
+      float* row = ring + slot * KW;
+      const uint32_t free_slot = slot == 0 ? 2u : slot - 1u;  // (q + 2) % 3 == (q - 1) % 3: row q-1's, read for the last time
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // rows q+1 and q+2 in flight while row q is reduced; the stream has n + 1 rows when there is noise to fetch
+      const uint32_t last = a.noise_on ? n : n - 1;
+      if (q + 2 <= last) {
+        request(q + 2, free_slot);
+        // one of the lane's normals per row, drawn while the rows are on their way and parked (raw) in the output row
+        if (a.noise_on && q < (uint32_t)KV) {
+          const float z = rng_normal(rs, &zig);
+          float* o = out;
+          asm volatile("" : "+s"(o));  // (as in request(): no hoisted per-lane address)
+          if (VLn::keeps(tid, q)) o[ln + 64 * (q / VLn::PER)] = z;
+          // (a store is one more vector-memory operation, younger than the three rows: rows q+1, q+2 and it may be pending)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES + 1) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        }
+      } else if (q + 1 <= last) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bool y = (s_nb[q] >> 31) != 0;
+      y = __builtin_amdgcn_readfirstlane((int)y) != 0;
+      const float e = y ? EPS : 1.0f - EPS;
+
+      // pass 1 (phi.cc:241-253), as update_phi_lds_kernel
+      float partial = 0.0f, lo = 1.0f;
+      auto pass1 = [&](auto link) {
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 pin = f32x2{row[ln + 128 * p], row[ln + 128 * p + 64]};
+          const f32x2 tt0 = pin * bf[p];
+          const f32x2 tt = decltype(link)::value ? tt0 + e : e - tt0;
+          const f32x2 pr = pi_a[p] * tt;
+          row[ln + 128 * p] = pr.x;
+          row[ln + 128 * p + 64] = pr.y;
+          VLn::chain(partial, pr.x);
+          VLn::chain(partial, pr.y);
+          lo = fminf(fminf(lo, fabsf(pr.x)), fabsf(pr.y));
+        }
+      };
+      if (y) pass1(std::true_type{});
+      else pass1(std::false_type{});
+      const float probs_sum = VLn::tree(partial);  // phi.cc:254-257
+
+      // pass 2 (phi.cc:259-263)
+      if (node_safe && lo >= kProbsLo && in_range(probs_sum, kPsumLo, kPsumHi)) {
+        const float rps = exact_rcp(probs_sum);
+        float ps = phi_sum;
+        asm volatile("" : "+v"(ps));  // keeps pi_a * phi_sum from being hoisted into KPT more registers
+        const f32x2 psum2 = f32x2{probs_sum, probs_sum}, rps2 = f32x2{rps, rps};
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 pr = f32x2{row[ln + 128 * p], row[ln + 128 * p + 64]};
+          f32x2 qv = div_exact3(pr, psum2, rps2);
+          qv = div_exact3(qv, pi_a[p] * ps, rden[p]);
+          grads[p] += qv - inv_phi_sum;
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const f32x2 den = pi_a[p] * phi_sum;
+          float q0 = row[ln + 128 * p] / probs_sum;
+          float q1 = row[ln + 128 * p + 64] / probs_sum;
+          q0 = q0 / den.x;
+          q1 = q1 / den.y;
+          grads[p] += f32x2{q0 - inv_phi_sum, q1 - inv_phi_sum};
+        }
+      }
+      slot = slot == 2 ? 0u : slot + 1u;
+    }
+    // the noise row (row n of the stream) sits in slot n % 3 == `slot`; it was requested two rows ago and may still be
+    // on its way (the last row's wait left it pending)
+    const float* zrow = ring + slot * KW;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // SGLD step, phi.cc:265-274
+    const float half = st.eps_t / 2;
+#pragma unroll
+    for (int p = 0; p < HP; ++p) {
+      asm volatile("" ::: "memory");  // one column pair at a time: keeps the 2 HP LDS reads of the noise row from being hoisted
+      const f32x2 phi_k = pi_a[p] * phi_sum;
+      const f32x2 ep = phi_k * st.eps_t;
+      f32x2 bb = f32x2{sqrtf(ep.x), sqrtf(ep.y)};
+      if (a.noise_on) bb = bb * f32x2{zrow[ln + 128 * p], zrow[ln + 128 * p + 64]};  // sqrt(eps_t * phi_k) * noise
+      const f32x2 ng = grads[p] * a.Nn;
+      f32x2 in = a.alpha - phi_k;
+      in = in + ng;
+      const f32x2 drift = in * half;
+      const f32x2 aa = phi_k + drift;
+      const f32x2 s2 = aa + bb;
+      const float v0 = fabsf(s2.x), v1 = fabsf(s2.y);
+      __builtin_nontemporal_store(v0 > 1e-24f ? v0 : 1e-24f, out + tid + 2 * L * p);
+      __builtin_nontemporal_store(v1 > 1e-24f ? v1 : 1e-24f, out + tid + 2 * L * p + L);
+    }
+  }
+  if (a.noise_on && tid < VL) a.seeds[(uint64_t)g * VL + tid] = rs;
   PHI_BLK(1);
 }
 
@@ -1915,6 +2130,19 @@ int launch_phi_lds(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStrea
   return AMMSB_OK;
 }
 
+template <int KPT, int VL = 64>
+int launch_phi_lds3(ammsb_ctx* ctx, const PhiArgs& a, uint32_t n_groups, hipStream_t s) {
+  const size_t lds = (size_t)3 * sizeof(float) * 64 * KPT + ((sizeof(uint32_t) * a.n + 15) & ~(size_t)15);
+  const bool one = a.pi.num_blocks == 1;
+  static const std::string name1 = ammsb_kname("update_phi_lds3_kernel<%d, %d, true>", KPT, VL);
+  static const std::string name0 = ammsb_kname("update_phi_lds3_kernel<%d, %d, false>", KPT, VL);
+  ctx->kernel_name[AMMSB_KN_PHI] = (one ? name1 : name0).c_str();
+  if (one) update_phi_lds3_kernel<KPT, VL, true><<<n_groups, 64, lds, s>>>(a);
+  else update_phi_lds3_kernel<KPT, VL, false><<<n_groups, 64, lds, s>>>(a);
+  AMMSB_LAUNCH_CHECK(ctx);
+  return AMMSB_OK;
+}
+
 // update_pi, phi.cc:177-197: copy phi_vec row into pi, WG_NORMALIZE it, phi_sum[node] = sum.
 template <int L, int KPT>
 __global__ __launch_bounds__(Group<L>::BLOCK) void update_pi_kernel(ammsb_rpm pi, float* phi_sum,
@@ -2364,6 +2592,11 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   if (a.group_begin >= a.group_end) return AMMSB_OK;
   const uint32_t n_groups = a.group_end - a.group_begin;
   hipStream_t s = as_stream(stream);
+  // AMMSB_PHI_LDS3=0|1: the three-slot K = 1024 kernel (update_phi_lds3_kernel) off / on (A/B runs; default below)
+  static const bool lds3 = [] {
+    const char* f = getenv("AMMSB_PHI_LDS3");
+    return f ? atoi(f) != 0 : AMMSB_PHI_LDS3_DEFAULT;
+  }();
   static const bool force_reg = [] {
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
@@ -2436,7 +2669,9 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
       // (tried: two rows per step at K = 1024 -- update_phi_lds2_kernel<16, 4, 2, VL>, which at wg 32 also halves the
       // swaps of the chain -- 2.19 against 1.88 ms at wg 32, 2.05 against 1.73 ms at wg 64 on C3: its 20 KiB of LDS
       // leave 8 waves per CU where the one-row kernel has 11.)
-      case 1024: return launch_phi_lds<16, 1, 2, 1, 32>(ctx, a, n_groups, s);
+      case 1024:
+        if (lds3 && a.n >= 32 * 2 / 1 / 2 + 2 + 16) return launch_phi_lds3<16, 32>(ctx, a, n_groups, s);  // n >= KV + 2, KV = 32
+        return launch_phi_lds<16, 1, 2, 1, 32>(ctx, a, n_groups, s);
       case 2048: return launch_phi_lds<32, 1, 2, 1, 32>(ctx, a, n_groups, s);
     }
   }
@@ -2476,6 +2711,7 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
           if (nb == 2) return launch_phi_lds<16, 1, 2, 2>(ctx, a, n_groups, s);
           // A/B: three rows in flight, 8 waves per CU -- C3 update_phi 1.76 -> 2.04 ms (profiles/r03_c3_ring_ab.log)
           if (ring == 4) return launch_phi_lds<16, 1, 4>(ctx, a, n_groups, s);
+          if (lds3 && ring == 0 && a.n >= 16 + 2) return launch_phi_lds3<16, 64>(ctx, a, n_groups, s);  // n >= KV + 2
           return launch_phi_lds<16, 1>(ctx, a, n_groups, s);
         }
         case 32: return launch_phi_lds<32, 1>(ctx, a, n_groups, s);

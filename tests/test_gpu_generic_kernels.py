@@ -222,3 +222,33 @@ def test_persistent_grid_update_phi(orc):
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "pair ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_three_slot_update_phi_kernel_is_bit_identical():
+    """update_phi_lds3_kernel (K = 1024, one wave per node, three ring slots in the LDS of two slots + the noise buffer:
+    the lane's normals travel through the node's output row; opt-in, AMMSB_PHI_LDS3=1, read once per process): every
+    K = 1024 update_phi parity case, the extreme-value cases, the > 65 535-node and group-shard cases and C3 at full size
+    run against the oracle with the kernel forced on, in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMMSB_PHI_LDS3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_fullsize.py"),
+                        "-k", "update_phi or c3_update_phi"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+    # and the forced kernel is the one that ran for the C3 row shape
+    code = ("import numpy as np, torch, __graft_entry__ as ge; ge.build()\n"
+            "import sys; sys.path.insert(0, 'tests')\n"
+            "import oracle_lib as orc; orc.build()\n"
+            "from mcmc_ammsb_gpu_amd import ops as hip\n"
+            "from test_gpu_parity import Problem\n"
+            "pr = Problem(orc, hip, 4096, 1024, 32, 300)\n"
+            "upd = hip.PhiUpdater(pr.ctx, pr.beta, pr.pi, pr.phi_sum, pr.dset, 300, (42, 43), 64, streaming_only=True)\n"
+            "upd(pr.nodes, pr.nb, 300); torch.cuda.synchronize()\n"
+            "print(pr.ctx.kernel_names()['update_phi'])\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "update_phi_lds3_kernel<16, 64, true>" in r.stdout, r.stdout + r.stderr
