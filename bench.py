@@ -65,9 +65,9 @@ def parse():
     ap.add_argument("--large", default=os.environ.get("AMMSB_BENCH_LARGE", "auto"), choices=["auto", "C5", "C5s", "none"],
                     help="large_configs of the default run: C5 (N=10M, K=4096: ~2 min of host set-up, 164 GB of pi), its "
                          "2M-vertex stand-in C5s, none; auto = C5 when HBM and host memory allow, else C5s")
-    ap.add_argument("--settle-s", type=float, default=1.5,
+    ap.add_argument("--settle-s", type=float, default=3.0,
                     help="seconds of untimed iterations BEFORE the warm-up steps: the package is at its power cap under "
-                         "update_phi and its power controller takes about a second to settle (profiles/README.md)")
+                         "update_phi and its power controller oscillates for the first ~3 s of load (profiles/README.md)")
     return ap.parse_args()
 
 
@@ -746,7 +746,7 @@ def main():
             "large_configs": large,
             "settle": {"seconds": args.settle_s, "steps": r.get("settle_steps", 0),
                        "why": "untimed iterations in front of the warm-up steps: update_phi holds the package at its power "
-                              "cap and the power controller needs about a second to settle (profiles/README.md)"},
+                              "cap and the power controller oscillates by +-4 % for the first ~3 s of load (profiles/README.md)"},
             "cpp_dropin": cpp,
         }
         print(json.dumps(out))
