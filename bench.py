@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--large", default=os.environ.get("AMMSB_BENCH_LARGE", "auto"), choices=["auto", "C5", "C5s", "none"],
                     help="large_configs of the default run: C5 (N=10M, K=4096: ~2 min of host set-up, 164 GB of pi), its "
                          "2M-vertex stand-in C5s, none; auto = C5 when HBM and host memory allow, else C5s")
+    ap.add_argument("--watchdog-s", type=float, default=-1.0,
+                    help="give up (exit 124, naming the phase and the rank on stderr and, from rank 0, as a JSON line) when "
+                         "one phase of the run makes no progress for this long; -1: 300 s with more than one rank (a "
+                         "collective one rank never joins blocks its peers for RCCL's own 10 minutes and says nothing "
+                         "about where), off with one; 0: off")
     ap.add_argument("--settle-s", type=float, default=3.0,
                     help="seconds of untimed iterations BEFORE the warm-up steps: the package is at its power cap under "
                          "update_phi and its power controller oscillates for the first ~3 s of load (profiles/README.md)")
@@ -78,6 +83,40 @@ def pick_wg(K, override, cap):
     while K // wg > cap and wg < 1024:  # keep <= cap columns per lane
         wg *= 2
     return wg
+
+
+class Watchdog:
+    """phase(name) says what the run is doing now; a phase that lasts longer than limit_s ends the process with the
+    phase's name.  For the first runs on more than one GPU: a rank stuck in a collective is otherwise silent."""
+
+    def __init__(self, limit_s, rank, world):
+        import threading
+        self.limit, self.rank, self.world = float(limit_s), rank, world
+        self.name, self.since, self.lock = "start", time.monotonic(), threading.Lock()
+        self.history = []
+        if self.limit > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def phase(self, name):
+        with self.lock:
+            now = time.monotonic()
+            self.history.append((self.name, round(now - self.since, 2)))
+            self.name, self.since = name, now
+
+    def _watch(self):
+        while True:
+            time.sleep(1.0)
+            with self.lock:
+                name, waited, hist = self.name, time.monotonic() - self.since, list(self.history[-8:])
+            if name == "done":
+                return
+            if waited > self.limit:
+                rec = {"error": "watchdog", "phase": name, "stuck_for_s": round(waited, 1), "rank": self.rank,
+                       "world": self.world, "phases_before": hist}
+                print("[bench] rank %d gave up: %s" % (self.rank, json.dumps(rec)), file=sys.stderr, flush=True)
+                if self.rank == 0:
+                    print(json.dumps(rec), flush=True)
+                os._exit(124)
 
 
 def loop_form(graphs):
@@ -287,8 +326,10 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
 
     # ---- settle: untimed iterations until the package's power controller has reached its steady state (the same
     # number of steps on every rank: decided by rank 0's clock, in whole chunks)
+    phase = getattr(args, "phase", lambda name: None)
     settle_steps = 0
     if settle_s > 0:
+        phase("%s: settle iterations" % workload)
         chunk = 100 if m >= 32768 else 2000
         t_s = time.perf_counter()
         while True:
@@ -305,6 +346,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
 
     # ---- perplexity latency (mean of ppx_calls, after one untimed call)
     ppx, ppx_ms = None, None
+    phase("%s: HeldoutPerplexity() latency" % workload)
     if ppx_calls > 0:
         lrn.HeldoutPerplexity()
         sync()
@@ -314,6 +356,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
         sync()
         ppx_ms = (time.perf_counter() - t0) * 1e3 / ppx_calls
 
+    phase("%s: warm-up + timed steps" % workload)
     lrn.Run(warmup)
     sync()
     phi = lrn.phiUpdater
@@ -526,6 +569,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    wd = Watchdog(args.watchdog_s if args.watchdog_s >= 0 else (300.0 if world > 1 else 0.0), rank, world)
+    args.phase = wd.phase
+    wd.phase("import torch")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the MI355X path has no CPU fallback")
@@ -536,6 +582,7 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
+    wd.phase("rendezvous (init_process_group, %s)" % backend)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -544,10 +591,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
+    wd.phase("build (rank 0) + first barrier")
     if rank == 0:
         ge.build()
     if world > 1:
         dist.barrier()
+    wd.phase("synthetic graph + edge sets (host)")
     import ammsb_pkg
     ammsb_pkg.load()
     from mcmc_ammsb_gpu_amd import hostlib
@@ -572,6 +621,7 @@ def main():
                                         graph_launch=graph, graph_timestamps=graph, phi_exchange=args.exchange)
     cfg = make_cfg(K, m, n, pick_wg(K, args.phi_wg, 16),   # K=1024 -> 64: the LDS-streamed kernel
                    pick_wg(K, args.beta_wg, 16), pick_wg(K, args.ppx_wg, 16), use_graph)
+    wd.phase("Learner() incl. the split calibration's update_phi / all-gather / point-to-point timings")
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
     lrn_E, lrn_H = int(ds.E), int(ds.heldout_edges.size)
@@ -588,6 +638,7 @@ def main():
             cpu = cpu_baseline(args, lrn, cfg, ds, m + 1)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
             cpu = {"value": None, "unit": "mini-batch edges/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    wd.phase("closing HeldoutPerplexity()")
     final_ppx = lrn.HeldoutPerplexity()
     loop_note = loop_form(graphs)
     fallback = getattr(lrn, "loop_fallbacks", 0)
@@ -599,6 +650,7 @@ def main():
         # what makes a multi-GPU line readable by itself: a traced (untimed) window right after the timed one -- per
         # non-link step where the time went (own blocks, replicated groups, each chunk's exchange and what of it was
         # hidden, update_pi, the gradient's all-gather), next to the calibration's prediction above
+        wd.phase("traced steps (phi_split.trace)")
         try:
             lrn.shard_trace = []
             traced = 0
@@ -615,6 +667,7 @@ def main():
                     "calibrated_full_exchange_ms": phi_split.get("xchg_ms"), "measured_exchange_ms": rep.get("exchange_ms")}
         except Exception as e:  # diagnostics must not cost the line
             phi_split["trace"] = {"error": repr(e)}
+    wd.phase("single-rank extras" if world == 1 else "closing the learner")
     lrn.close()
     del lrn
     torch.cuda.empty_cache()
@@ -749,6 +802,7 @@ def main():
                               "cap and the power controller oscillates by +-4 % for the first ~3 s of load (profiles/README.md)"},
             "cpp_dropin": cpp,
         }
+        wd.phase("done")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

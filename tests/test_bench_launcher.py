@@ -57,6 +57,24 @@ def test_spawned_children_failure_is_relayed():
     assert '"metric"' not in out.stdout
 
 
+def test_watchdog_names_the_phase_a_rank_is_stuck_in():
+    """A rank blocked in a collective its peers never join says nothing for RCCL's ten minutes; the bench's watchdog
+    ends the process with the phase's name (rank 0 also as a JSON line on stdout) and exit code 124."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; wd = bench.Watchdog(0.5, 0, 8); "
+            "wd.phase('Learner() incl. the split calibration'); time.sleep(30)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 124
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["error"] == "watchdog" and rec["phase"].startswith("Learner()") and rec["rank"] == 0 and rec["world"] == 8
+    assert "gave up" in out.stderr
+    # a phase change in time keeps the run alive; "done" stops the watching
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; wd = bench.Watchdog(1.0, 1, 2)\n"
+            "for i in range(4):\n    wd.phase('p%%d' %% i); time.sleep(0.4)\n"
+            "wd.phase('done'); time.sleep(1.5); print('alive')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "alive", out.stderr
+
+
 @pytest.mark.gpu
 def test_plain_bench_two_ranks_end_to_end():
     """`python bench.py --gpus 2 --workload C1` exactly as the driver types it (no launcher): the parent starts the two
