@@ -42,18 +42,31 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _torch_stream():
+    """The torch.cuda.Stream object of the same cache (events are recorded on / waited for by stream OBJECTS: an
+    Event.record() without one asks torch for the current stream, ~8 us, six times per iteration of the multi-GPU
+    schedule)."""
+    stack = getattr(_tls, "tstack", None)
+    if stack:
+        return stack[-1]
+    return torch.cuda.current_stream()
+
+
 class pin_current_stream:
     """with pin_current_stream(): ...  -- the stream that is current on entry is used for every launch of this
     thread inside the block (unless `stream(s)` switches), without asking torch again."""
 
     def __enter__(self):
         if not hasattr(_tls, "stack"):
-            _tls.stack = []
-        _tls.stack.append(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _tls.stack, _tls.tstack = [], []
+        cur = torch.cuda.current_stream()
+        _tls.stack.append(C.c_void_p(cur.cuda_stream))
+        _tls.tstack.append(cur)
         return self
 
     def __exit__(self, *exc):
         _tls.stack.pop()
+        _tls.tstack.pop()
         return False
 
 
@@ -67,12 +80,14 @@ class _StreamScope:
     def __enter__(self):
         self.tc.__enter__()
         if not hasattr(_tls, "stack"):
-            _tls.stack = []
+            _tls.stack, _tls.tstack = [], []
         _tls.stack.append(C.c_void_p(self.s.cuda_stream))
+        _tls.tstack.append(self.s)
         return self
 
     def __exit__(self, *exc):
         _tls.stack.pop()
+        _tls.tstack.pop()
         return self.tc.__exit__(*exc)
 
 
@@ -760,7 +775,7 @@ def new_event():
 
 
 def record_event(ev):
-    ev.record()  # on torch's current stream
+    ev.record(_torch_stream())  # on the current stream
 
 
 def sync_event(ev):
@@ -768,7 +783,7 @@ def sync_event(ev):
 
 
 def wait_event(ev):
-    ev.wait()  # torch's current stream waits for the event
+    ev.wait(_torch_stream())  # the current stream waits for the event
 
 
 def synchronize():
@@ -778,7 +793,7 @@ def synchronize():
 def timing_mark():
     """A timing event recorded on torch's current stream (the multi-GPU step trace, Learner.shard_trace)."""
     ev = torch.cuda.Event(enable_timing=True)
-    ev.record()
+    ev.record(_torch_stream())
     return ev
 
 
