@@ -160,6 +160,20 @@ int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, cons
                      const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
                      uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream);
 
+/* ammsb_update_pi over nodes[0 .. n_edges] and ammsb_beta_grads over edges [0, n_edges) as ONE launch, for
+ * node-stratified mini-batches (edge t = (nodes[0], nodes[t + 1]) in either order, n_nodes = n_edges + 1: what the
+ * device sampler's Node strategies produce): every pi row of the mini-batch is normalised from its phi_vec row as the
+ * gradient consumes it and written once -- update_pi_kernel's arithmetic, phi.cc:177-197, and the values
+ * calculate_grads_partial (beta.cc:145-233) would have read back: bit-identical to the two calls, one launch and one
+ * pass over the rows less.  Only for shapes ammsb_can_fuse_pi_beta() accepts (phi wg == beta wg in {32, 64} and
+ * K <= 2 wg or K in {256, 512, 1024}); AMMSB_EINVAL otherwise.  The descriptor loop (ammsb_loop) uses the same kernel;
+ * the multi-GPU schedule uses this entry so that every rank holds the whole gradient and needs no collective for it. */
+int ammsb_can_fuse_pi_beta(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg);
+int ammsb_update_pi_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                               float* phi_sum, const float* phi_vec, const uint32_t* nodes,
+                               const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges, uint32_t wg,
+                               float* grads_out, void* stream);
+
 /* Multi-GPU gradient reduction after the all-gather of the R per-rank [cols] vectors into in[R, cols]:
  * out[c] = in[0][c] + in[1][c] + ... in ascending rank order (a fixed association, identical on every rank). */
 int ammsb_sum_rows_f32(ammsb_ctx* ctx, const float* in, uint32_t rows, uint32_t cols, float* out, void* stream);

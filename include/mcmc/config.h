@@ -103,6 +103,14 @@ struct Config {
   // group exchanged.
   uint32_t phi_chunks;
   Float phi_replicate;
+  // new (multi-GPU): a mini-batch with at most this many edges is not cut over the ranks -- every rank computes its
+  // whole gradient (a link mini-batch has a few dozen edges: the all-gather of the partial sums would cost more than
+  // the gradient, and the result is then the single-GPU one bit for bit)
+  uint32_t beta_shard_min_edges;
+  // new (multi-GPU): 0 = "sharded" (edge slices, all-gather of the partial sums, added in rank order), 1 =
+  // "replicated" (every rank the whole gradient: no collective, theta bit-identical to one GPU's), -1 = auto:
+  // replicated where update_pi can be folded into the gradient launch (device-sampled Node mini-batches, K <= 1024)
+  int beta_grads;
 
   Config();
 };

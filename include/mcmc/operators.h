@@ -248,6 +248,11 @@ class BetaUpdater {
   void BeginCall() { ++count_calls_; }
   void CalculateGrads(clcuda::Buffer<Edge>* edges, uint32_t num_edges, uint32_t edge_begin, uint32_t edge_end, Float* out);
   void UpdateTheta(Float scale, const Float* grads);
+  // PhiUpdater::UpdatePi over nodes[0 .. num_edges] and CalculateGrads over the whole mini-batch as one launch
+  // (ammsb_update_pi_beta_grads: node-stratified mini-batches, shapes CanFuseUpdatePi accepts).  Enqueue-only.
+  bool CanFuseUpdatePi(uint32_t phi_local) const;
+  void UpdatePiAndGrads(clcuda::Buffer<Float>& phi_sum, clcuda::Buffer<Float>& phi_vec, clcuda::Buffer<Vertex>& nodes,
+                        clcuda::Buffer<Edge>* edges, uint32_t num_edges, Float* out);
   random::OpenClRandom& Rand() { return rand_; }  // for the captured-graph loop (ammsb_loop)
   uint32_t& CountCalls() { return count_calls_; }
   uint32_t Local() const { return local_; }

@@ -85,6 +85,8 @@ SIGNATURES = {
     "ammsb_update_phi_occupancy": [_vp, _u32, _P(C.c_int), _P(C.c_int)],
     "ammsb_update_pi": [_vp, _P(Rpm), _vp, _vp, _vp, _u32, _u32, _vp],
     "ammsb_beta_grads": [_vp, _vp, _vp, _P(Rpm), _P(SetDesc), _vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    "ammsb_can_fuse_pi_beta": [_vp, _u32, _u32],
+    "ammsb_update_pi_beta_grads": [_vp, _vp, _vp, _P(Rpm), _vp, _vp, _vp, _P(SetDesc), _vp, _u32, _u32, _vp, _vp],
     "ammsb_sum_rows_f32": [_vp, _vp, _u32, _u32, _vp, _vp],
     "ammsb_update_theta": [_vp, _vp, _vp, _vp, _u32, _f32, _vp, _u32, _vp],
     "ammsb_beta_from_theta": [_vp, _vp, _vp, _vp],

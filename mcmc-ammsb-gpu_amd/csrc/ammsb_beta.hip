@@ -1422,8 +1422,9 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.stamps = desc ? stamps : nullptr;
   a.fuse = ammsb_pi_fusion{nullptr, nullptr, nullptr, nullptr};
   if (fuse && fuse->phi_vec) {
-    AMMSB_CHECK_ARG(ctx, desc && fuse->phi_sum && fuse->nodes && beta_fuse_shape(ctx, wg),
-                    "update_pi fusion needs a descriptor and a shape the fused kernels take");
+    // (the slots of a fused launch write every pi row of the mini-batch exactly once: only over the whole batch)
+    AMMSB_CHECK_ARG(ctx, fuse->phi_sum && fuse->nodes && beta_fuse_shape(ctx, wg) && (desc || (edge_begin == 0 && edge_end == n_edges)),
+                    "update_pi fusion needs the whole mini-batch and a shape the fused kernels take");
     a.fuse = *fuse;
   }
   const uint32_t span = edge_end - edge_begin;
@@ -1486,6 +1487,28 @@ extern "C" int ammsb_beta_grads(ammsb_ctx* ctx, const float* theta, const float*
                                 uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out, void* stream) {
   return beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges, edge_begin, edge_end, wg, grads_out,
                            nullptr, true, nullptr, stream);
+}
+
+extern "C" int ammsb_can_fuse_pi_beta(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg) {
+  return ammsb_beta_can_fuse_pi(ctx, phi_wg, beta_wg) ? 1 : 0;
+}
+
+// ammsb_update_pi over nodes[0 .. n_edges] followed by ammsb_beta_grads over the whole mini-batch, as ONE launch (the
+// descriptor loop's fused kernel, here with immediate sizes): for the callers outside the loop -- the multi-GPU
+// schedule, where every rank then holds the whole gradient and no collective is needed for it.
+extern "C" int ammsb_update_pi_beta_grads(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
+                                          float* phi_sum, const float* phi_vec, const uint32_t* nodes,
+                                          const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
+                                          uint32_t wg, float* grads_out, void* stream) {
+  AMMSB_CHECK_ARG(ctx, ctx && phi_sum && phi_vec && nodes && n_edges > 0, "null argument / empty mini-batch");
+  if (!beta_fuse_shape(ctx, wg)) {
+    snprintf(ctx->err, sizeof ctx->err, "ammsb_update_pi_beta_grads: K=%u at wg=%u is not a shape the fused kernels take "
+             "(ammsb_can_fuse_pi_beta)", (unsigned)ctx->params.K, wg);
+    return AMMSB_EINVAL;
+  }
+  const ammsb_pi_fusion fuse = {phi_vec, phi_sum, nodes, nullptr};
+  return beta_grads_common(ctx, theta, beta, pi, training_set, edges, n_edges, 0, n_edges, wg, grads_out, nullptr, true,
+                           nullptr, stream, &fuse);
 }
 
 int ammsb_beta_grads_d(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,

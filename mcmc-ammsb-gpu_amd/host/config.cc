@@ -54,6 +54,8 @@ Config::Config() {  // config.h:69-101
   sample_seed[1] = 846930886u;
   phi_chunks = 4;
   phi_replicate = -1;
+  beta_shard_min_edges = 4096;
+  beta_grads = -1;
 }
 
 std::ostream& operator<<(std::ostream& out, const ulong2& v) { return out << v[0] << "," << v[1]; }

@@ -435,8 +435,9 @@ void Learner::CalibrateSplit() {
 // Per chunk: update_phi over the own block on the main stream, then that chunk's in-place all-gather (region
 // [base, base + world * cc), which can reach past G: owners park their tail rows first and hand them out afterwards)
 // on the exchange stream, beside the next block and the replicated groups.  A chunk whose live groups all sit in rank
-// 0's block (a link mini-batch of a low-degree vertex) is a broadcast.  pi is bit-identical to a single rank's; theta
-// differs by the association of the gradient sum (per-rank partials summed in rank order).
+// 0's block (a link mini-batch of a low-degree vertex) is a broadcast.  pi is bit-identical to a single rank's; so is
+// theta when every rank computes the whole gradient (Config::beta_grads), else it differs by the association of the
+// gradient sum (per-rank partials summed in rank order).
 void Learner::StepSharded(Sample& s, Float weight) {
   Exchange& x = *cfg_.exchange;
   const uint32_t R = static_cast<uint32_t>(x.world()), r = static_cast<uint32_t>(x.rank()), Cc = cc_, g0 = g_rep_;
@@ -486,16 +487,28 @@ void Learner::StepSharded(Sample& s, Float weight) {
                                  hipMemcpyDeviceToDevice, stream),
                   "hipMemcpyAsync");
   }
-  phiUpdater_.UpdatePi(s.dev_nodes, n);
-
-  betaUpdater_.BeginCall();
+  // The gradient (mcmc-ammsb-gpu_amd/learner.py, _run): cut over the ranks only in "sharded" mode and only for
+  // mini-batches worth a collective; otherwise every rank computes all of it -- with update_pi folded into the same
+  // launch where the shape and the mini-batch (edge t = (nodes[0], nodes[t + 1]): the device sampler's) allow.
   const uint32_t ne = s.num_edges, per = (ne + R - 1) / R;
+  const bool fusable = cfg_.device_sampling && betaUpdater_.CanFuseUpdatePi(phiUpdater_.Local());
+  const bool replicated = cfg_.beta_grads == 1 || (cfg_.beta_grads < 0 && fusable);
+  const bool shard = !replicated && ne > cfg_.beta_shard_min_edges;
+  const bool fuse = !shard && fusable && n == ne + 1;
+  if (!fuse) phiUpdater_.UpdatePi(s.dev_nodes, n);
+  betaUpdater_.BeginCall();
   Float* local = betaUpdater_.GetGrads().data();
-  betaUpdater_.CalculateGrads(&s.dev_edges, ne, std::min(r * per, ne), std::min((r + 1) * per, ne), local);
-  x.AllGather(local, all_grads_->data(), 2 * row, stream);
-  ThrowIfError(ctx_.get(), ammsb_sum_rows_f32(ctx_.get(), all_grads_->data(), R, 2 * K, grads_sum_->data(), stream),
-               "ammsb_sum_rows_f32");
-  betaUpdater_.UpdateTheta(weight, grads_sum_->data());
+  if (shard) {
+    betaUpdater_.CalculateGrads(&s.dev_edges, ne, std::min(r * per, ne), std::min((r + 1) * per, ne), local);
+    x.AllGather(local, all_grads_->data(), 2 * row, stream);
+    ThrowIfError(ctx_.get(), ammsb_sum_rows_f32(ctx_.get(), all_grads_->data(), R, 2 * K, grads_sum_->data(), stream),
+                 "ammsb_sum_rows_f32");
+    betaUpdater_.UpdateTheta(weight, grads_sum_->data());
+  } else {
+    if (fuse) betaUpdater_.UpdatePiAndGrads(phi_, phiUpdater_.GetPhiVec(), s.dev_nodes, &s.dev_edges, ne, local);
+    else betaUpdater_.CalculateGrads(&s.dev_edges, ne, 0, ne, local);
+    betaUpdater_.UpdateTheta(weight, local);
+  }
   if (!cfg_.async_launch) queue_.Finish();
 }
 

@@ -481,6 +481,20 @@ void BetaUpdater::CalculateGrads(clcuda::Buffer<Edge>* edges, uint32_t num_edges
                "ammsb_beta_grads");
 }
 
+bool BetaUpdater::CanFuseUpdatePi(uint32_t phi_local) const {
+  return ammsb_can_fuse_pi_beta(ctx_.get(), phi_local, local_) != 0;
+}
+
+void BetaUpdater::UpdatePiAndGrads(clcuda::Buffer<Float>& phi_sum, clcuda::Buffer<Float>& phi_vec,
+                                   clcuda::Buffer<Vertex>& nodes, clcuda::Buffer<Edge>* edges, uint32_t num_edges,
+                                   Float* out) {
+  ThrowIfError(ctx_.get(),
+               ammsb_update_pi_beta_grads(ctx_.get(), theta_.data(), beta_.data(), &pi_->Get(), phi_sum.data(),
+                                          phi_vec.data(), nodes.data(), &trainingSet_->Get(), edges->data(), num_edges,
+                                          local_, out, queue_.stream()),
+               "ammsb_update_pi_beta_grads");
+}
+
 void BetaUpdater::UpdateTheta(Float scale, const Float* grads) {
   ThrowIfError(ctx_.get(),
                ammsb_update_theta(ctx_.get(), theta_.data(), beta_.data(), grads, count_calls_, scale, rand_.Get(), 0,

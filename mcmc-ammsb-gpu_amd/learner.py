@@ -77,6 +77,17 @@ class Config:
         self.phi_replicate = "auto"                  # (new) multi-GPU: fraction of groups every rank computes itself
         self.phi_exchange = "auto"                   # (new) multi-GPU: "collective" (all-gather) | "p2p" (direct peer
                                                      # sends, one per link) | "auto" (time both at start-up)
+        self.beta_grads = "auto"                     # (new) multi-GPU: "sharded" (edge slices + all-gather of the partial
+                                                     # sums, rank-ordered) | "replicated" (every rank the whole
+                                                     # gradient: no collective, theta bit-identical to one GPU's) |
+                                                     # "auto": replicated where update_pi can be folded into the
+                                                     # gradient launch (K <= 1024, device-sampled Node batches: the one
+                                                     # launch costs less than update_pi + a slice + the all-gather)
+        self.beta_shard_min_edges = 4096             # (new) multi-GPU: a mini-batch with at most this many edges is not
+                                                     # cut over the ranks -- every rank computes its whole gradient (a link
+                                                     # mini-batch has a few dozen edges: the all-gather of the partial
+                                                     # sums would cost more than the gradient, and the result is then
+                                                     # the single-GPU one bit for bit)
         self.force_exchange = False                  # (new, tests) take the multi-rank code path even with one rank
         # (new) whole iterations as captured hipGraphs (include/ammsb.h ammsb_loop): "auto" = whenever it applies
         # (device sampling, one rank); False keeps the eager launch-by-launch loop (the parity form); results are
@@ -225,6 +236,17 @@ class Learner:
             self.dev_sampler = ops.DeviceMiniBatchSampler(c, off, tgt, self.trainingSet, self.heldoutSet,
                                                           cfg.mini_batch_size, cfg.device_sampling_seed,
                                                           heldout_degree=hdeg)
+        # multi-GPU: how the beta gradient is computed (Config.beta_grads)
+        self.grads_mode, self.grads_fused = "sharded", False
+        if self.sharded:
+            want = str(getattr(cfg, "beta_grads", "auto"))
+            if want not in ("auto", "sharded", "replicated"):
+                raise AmmsbError("beta_grads must be auto, sharded or replicated (got %r)" % (want,))
+            fusable = (self.dev_sampler is not None and cfg.strategy in ("Node", "NodeLink", "NodeNonLink")
+                       and hasattr(self.betaUpdater, "can_fuse_update_pi")
+                       and self.betaUpdater.can_fuse_update_pi(self.phiUpdater))
+            self.grads_mode = "replicated" if want == "replicated" or (want == "auto" and fusable) else "sharded"
+            self.grads_fused = fusable
         if self.sharded:
             # the replicated groups run on their own stream next to the exchanged blocks: with 8 ranks a block is
             # ~1800 single-wave nodes, well under what the chip holds, and the two launches fill it together
@@ -445,6 +467,11 @@ class Learner:
                     prev = ev
         out = {k: float(np.mean(v)) for k, v in acc.items()}
         out["steps"] = len(big)
+        out["gradient"] = ("replicated: every rank computes the whole gradient%s -- no collective; grads_local_ms is that "
+                           "launch, grad_allgather_ms ~ 0" % (", update_pi folded into its launch (update_pi_ms ~ 0)"
+                                                               if self.grads_fused else "")
+                           if self.grads_mode == "replicated" else
+                           "sharded: edge slices, all-gather of the R partial sums, added in rank order")
         per_chunk = []
         tot_ms = 0.0
         for c in sorted(chunks):
@@ -647,16 +674,30 @@ class Learner:
             self._mark(rec, "begin")
             self._phi_sharded(s, n_nodes, rec)
             self._mark(rec, "phi_end")
-            phi.update_pi(s.dev_nodes, n_nodes)
+            beta = self.betaUpdater
+            # multi-GPU: the gradient is cut over the ranks only in "sharded" mode and only for mini-batches worth a
+            # collective; otherwise every rank computes all of it -- with update_pi folded into the same launch where
+            # the shape and the mini-batch (edge t = (nodes[0], nodes[t + 1])) allow
+            shard = (self.sharded and self.grads_mode == "sharded"
+                     and n_edges > int(getattr(cfg, "beta_shard_min_edges", 0)))
+            fuse = self.sharded and not shard and self.grads_fused and n_nodes == n_edges + 1
+            if not fuse:
+                phi.update_pi(s.dev_nodes, n_nodes)
             self._mark(rec, "pi_end")
 
             # betaUpdater_(edges, n, weight)  -- beta.cc:334-384
-            beta = self.betaUpdater
             beta.count_calls += 1
-            e_lo, e_hi = self._edge_range(n_edges)
-            local = beta.calculate_grads(s.dev_edges, n_edges, e_lo, e_hi)
-            self._mark(rec, "grads_local")
-            total = self._reduce_grads(local)
+            if shard:
+                e_lo, e_hi = self._edge_range(n_edges)
+                local = beta.calculate_grads(s.dev_edges, n_edges, e_lo, e_hi)
+                self._mark(rec, "grads_local")
+                total = self._reduce_grads(local)
+            elif fuse:
+                total = beta.update_pi_and_grads(phi, s.dev_nodes, s.dev_edges, n_edges)
+                self._mark(rec, "grads_local")
+            else:
+                total = beta.calculate_grads(s.dev_edges, n_edges, 0, n_edges)
+                self._mark(rec, "grads_local")
             self._mark(rec, "grads_reduced")
             beta.update_theta(weight, total)
             self._mark(rec, "end")

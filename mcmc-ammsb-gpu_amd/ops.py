@@ -390,6 +390,22 @@ class BetaUpdater:
                                        int(min(edge_end, num_edges)), self.local, _ptr(g), _stream()))
         return g
 
+    def can_fuse_update_pi(self, phi_updater):
+        """Whether update_pi_and_grads takes this context's (K, work-group sizes)."""
+        c = self.ctx
+        return bool(c.lib.ammsb_can_fuse_pi_beta(c.handle, int(phi_updater.local), self.local))
+
+    def update_pi_and_grads(self, phi_updater, nodes, edges, num_edges, out=None):
+        """phi_updater.update_pi(nodes, num_edges + 1) and calculate_grads(edges, num_edges) as one launch
+        (ammsb_update_pi_beta_grads): node-stratified mini-batches only -- edge t = (nodes[0], nodes[t + 1])."""
+        c = self.ctx
+        g = self.grads if out is None else out
+        c.check(c.lib.ammsb_update_pi_beta_grads(c.handle, _ptr(self.theta), _ptr(self.beta), C.byref(self.pi.desc),
+                                                 _ptr(phi_updater.phi), _ptr(phi_updater.phi_vec), _ptr(nodes),
+                                                 C.byref(self.set.desc), _ptr(edges), int(num_edges), self.local,
+                                                 _ptr(g), _stream()))
+        return g
+
     def update_theta(self, scale, grads=None):
         c = self.ctx
         g = self.grads if grads is None else grads

@@ -178,8 +178,20 @@ def _heldout_edges(d):
     return 2 * (edges.size - math.ceil((1 - ratio / 2) * edges.size))  # links + as many fake pairs (data.cc:87-126)
 
 
-def _compare(single_ck, rank_ck, K, H):
+SHARDED_GRADS = ("--beta-grads", "0", "--beta-shard-min-edges", "0")  # every mini-batch's gradient cut over the ranks
+
+
+def _compare(single_ck, rank_ck, K, H, exact=False):
     ref = _records(single_ck)
+    if exact:  # every rank computed the whole gradient: the checkpoint is the single rank's, byte for byte
+        got = _records(rank_ck)
+        assert len(got) == len(ref)
+        for i, (a, b) in enumerate(zip(ref, got)):
+            if len(a) >= 200:
+                assert a == b, "record %d (%d bytes) differs" % (i, len(a))
+            elif i < 2:
+                assert a[-8 * K:] == b[-8 * K:], "theta / beta differ"
+        return
     for ck in [rank_ck]:
         got = _records(ck)
         assert len(got) == len(ref)
@@ -208,8 +220,10 @@ def _dataset(tmp_path, N, deg, flags, seed):
     return d
 
 
-def _run_case(tmp_path, d, world, flags, iters, interval, ppx_rtol, tag, timeout=900, split=("--phi-replicate", "0", "--phi-chunks", "1")):
-    # (`split`: the ranks' sharding flags -- default: every group exchanged in one chunk, the plain schedule)
+def _run_case(tmp_path, d, world, flags, iters, interval, ppx_rtol, tag, timeout=900,
+              split=("--phi-replicate", "0", "--phi-chunks", "1") + SHARDED_GRADS):
+    # (`split`: the ranks' sharding flags -- default: every group exchanged in one chunk and the gradient cut over the
+    # ranks, the plain schedule)
     common = [EXE, "--load-data", "1", "--load-file", d] + flags + ["-x", str(iters), "-i", str(interval)]
     ck1 = str(tmp_path / (tag + "single.ckpt"))
     one = subprocess.run(common + ["--checkpoint-out", ck1], capture_output=True, text=True, timeout=timeout)
@@ -257,9 +271,9 @@ def test_three_ranks_full_blocks_and_tail_rows(built, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("split,tag", [
-    (("--phi-replicate", "0.3", "--phi-chunks", "2"), "hybrid"),      # 30 % of the groups replicated, two overlapped chunks per rank
-    (("--phi-replicate", "0.00003", "--phi-chunks", "3"), "mixed"),   # ONE replicated group: replicated and exchanged tail rows
-    (("--phi-replicate", "-1"), "auto"),                              # measured at start-up (whatever it comes out as)
+    (("--phi-replicate", "0.3", "--phi-chunks", "2") + SHARDED_GRADS, "hybrid"),      # 30 % of the groups replicated, two overlapped chunks per rank
+    (("--phi-replicate", "0.00003", "--phi-chunks", "3") + SHARDED_GRADS, "mixed"),   # ONE replicated group: replicated and exchanged tail rows
+    (("--phi-replicate", "-1") + SHARDED_GRADS, "auto"),                              # measured at start-up (whatever it comes out as)
 ])
 def test_hybrid_split_and_chunked_exchange(built, tmp_path, split, tag):
     """The tuned schedule of learner.py behind the C++ API (Config::phi_replicate / phi_chunks): replicated prefix,
@@ -273,3 +287,21 @@ def test_hybrid_split_and_chunked_exchange(built, tmp_path, split, tag):
     _compare(*_run_case(tmp_path, d, 3, flags + ["-s", "NodeNonLink"], iters=1, interval=1, ppx_rtol=1e-5, tag=tag + "a",
                         split=split), K, _heldout_edges(d))
     _run_case(tmp_path, d, 2, flags + ["-s", "Node"], iters=6, interval=3, ppx_rtol=3e-3, tag=tag + "b", split=split)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,wg,extra,tag", [
+    (32, 32, ("--device-sampling", "1", "--async", "1"), "fused"),   # update_pi folded into the gradient launch (default: auto)
+    (256, 64, ("--device-sampling", "1", "--async", "1"), "fused256"),
+    (32, 32, ("--beta-grads", "1"), "host"),                         # host-sampled mini-batches: separate launches
+])
+def test_replicated_gradient_is_the_single_rank_run_byte_for_byte(built, tmp_path, K, wg, extra, tag):
+    """Config::beta_grads: every rank computes the whole gradient (no collective for it) -- after six iterations of
+    link and non-link mini-batches the two-rank checkpoint, theta and beta included, is the single rank's."""
+    m = "16384" if K == 32 else "4096"
+    flags = ["-k", str(K), "-m", m, "-n", "16", "-r", "0.02", "--phi-wg", str(wg), "--beta-wg", str(wg), "--ppx-wg", str(wg)]
+    flags += list(extra)
+    d = _dataset(tmp_path, 60000, 10, flags, seed=11)
+    ck = _run_case(tmp_path, d, 2, flags + ["-s", "Node"], iters=6, interval=3, ppx_rtol=1e-6, tag=tag,
+                   split=("--phi-replicate", "0.3", "--phi-chunks", "2"))
+    _compare(*ck, K, _heldout_edges(d), exact=True)

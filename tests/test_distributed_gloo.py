@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, outdir, case, chunks=4, rep="auto"):
+def _run(rank, world, port, outdir, case, chunks=4, rep="auto", grads="sharded"):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -42,7 +42,9 @@ def _run(rank, world, port, outdir, case, chunks=4, rep="auto"):
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
     cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=32, beta_wg_size=32,
                                            ppx_wg_size=32, strategy="Node", sample_parallel=True, phi_chunks=chunks,
-                                           phi_replicate=rep)
+                                           phi_replicate=rep, beta_grads=grads,
+                                           # (sharded: every mini-batch, link batches included, takes the collective)
+                                           beta_shard_min_edges=0 if grads == "sharded" else 4096)
     lrn = learner.Learner(cfg, ds, ops=oracle_ops, rank=rank, world_size=world, group=group)
     p0 = lrn.HeldoutPerplexity()
     if world > 1:
@@ -75,7 +77,10 @@ def _run(rank, world, port, outdir, case, chunks=4, rep="auto"):
     ((3000, 32, 256, 8, 6), 2, 0.002),       # replicated prefix shorter than a link batch: both kinds of group in one step
     ((150000, 32, 70000, 2, 2), 2, 0.00003), # 1 replicated group, 4465 tail rows: replicated AND exchanged tail rows
 ], ids=["small", "tail-1chunk", "tail-3chunks", "replicate-30pct", "replicate-tiny", "mixed-tail"])
-def test_world2_matches_single_process(tmp_path, case, chunks, rep):
+@pytest.mark.parametrize("grads", ["sharded", "replicated"])
+def test_world2_matches_single_process(tmp_path, case, chunks, rep, grads):
+    if grads == "replicated" and (chunks, rep) not in ((4, "auto"), (2, 0.3)):
+        pytest.skip("the replicated gradient is covered on two of the splits")
     import torch.multiprocessing as mp
     import __graft_entry__ as ge
     ge.build()
@@ -83,7 +88,7 @@ def test_world2_matches_single_process(tmp_path, case, chunks, rep):
     _run(0, 1, 0, out, case)
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, rep)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, rep, grads)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -92,6 +97,9 @@ def test_world2_matches_single_process(tmp_path, case, chunks, rep):
     one = np.load(os.path.join(out, "w1_r0.npz"))
     r0 = np.load(os.path.join(out, "w2_r0.npz"))
     r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    if grads == "replicated":  # every rank the whole gradient (Config.beta_grads): the single-process run bit for bit
+        for k in ("pi", "phi", "theta", "beta"):
+            assert np.array_equal(r0[k], one[k]), k
     # replicas stay identical
     for k in ("pi", "phi", "theta", "beta", "ppx", "edges"):
         assert np.array_equal(r0[k], r1[k]), k

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, outdir, case, chunks, device_sampling, rep):
+def _run(rank, world, port, outdir, case, chunks, device_sampling, rep, grads="sharded"):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,8 +40,11 @@ def _run(rank, world, port, outdir, case, chunks, device_sampling, rep):
     ds = hostlib.Dataset.robust(N, edges, heldout_ratio=0.05, rand_seed=7)
     cfg = learner.Config.from_cli_defaults(K=K, mini_batch_size=m, num_node_sample=n, phi_wg_size=64, beta_wg_size=64,
                                            ppx_wg_size=64, strategy="Node", phi_chunks=chunks,
-                                           device_sampling=device_sampling, phi_replicate=rep)
+                                           device_sampling=device_sampling, phi_replicate=rep, beta_grads=grads,
+                                           beta_shard_min_edges=0 if grads == "sharded" else 4096)
     lrn = learner.Learner(cfg, ds, rank=rank, world_size=world, group=None)
+    if world > 1 and grads != "sharded":
+        assert lrn.grads_mode == "replicated" and lrn.grads_fused == bool(device_sampling)
     p0 = lrn.HeldoutPerplexity()
     lrn.Run(1)
     pi1 = lrn.pi.host()
@@ -58,13 +61,19 @@ def _run(rank, world, port, outdir, case, chunks, device_sampling, rep):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,chunks,device_sampling,rep", [
-    ((3000, 256, 256, 8, 6), 4, False, 0.0),      # K = 256: LDS-streamed phi / beta kernels; first block only -> broadcasts
-    ((150000, 64, 70000, 2, 3), 3, False, 0.0),   # > 65535 mini-batch nodes: tail rows, 3 overlapped chunks
-    ((150000, 64, 16384, 4, 4), 2, True, 0.25),   # device-side mini-batch sampler; a quarter of the groups replicated
-    ((150000, 64, 70000, 2, 3), 2, False, "auto"),  # split calibrated at start-up from a timed launch and exchange
-], ids=["small", "tail-3chunks", "device-sampling", "auto-split"])
-def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling, rep):
+@pytest.mark.parametrize("case,chunks,device_sampling,rep,grads", [
+    ((3000, 256, 256, 8, 6), 4, False, 0.0, "sharded"),      # K = 256: LDS-streamed phi / beta kernels; first block only -> broadcasts
+    ((150000, 64, 70000, 2, 3), 3, False, 0.0, "sharded"),   # > 65535 mini-batch nodes: tail rows, 3 overlapped chunks
+    ((150000, 64, 16384, 4, 4), 2, True, 0.25, "sharded"),   # device-side mini-batch sampler; a quarter of the groups replicated
+    ((150000, 64, 70000, 2, 3), 2, False, "auto", "sharded"),  # split calibrated at start-up from a timed launch and exchange
+    # every rank the whole gradient (Config.beta_grads): no collective for it, and the run is the single-GPU one BIT FOR
+    # BIT -- with update_pi folded into the gradient launch for device-sampled mini-batches ("auto" picks that) ...
+    ((150000, 64, 16384, 4, 6), 2, True, 0.25, "auto"),
+    ((30000, 256, 4096, 8, 6), 2, True, 0.1, "auto"),        # ... at K = 256 (the LDS-streamed fused kernel) ...
+    ((3000, 256, 256, 8, 6), 4, False, 0.0, "replicated"),   # ... and as separate launches for host-sampled ones
+], ids=["small", "tail-3chunks", "device-sampling", "auto-split", "replicated-fused-k64", "replicated-fused-k256",
+        "replicated-host-sampled"])
+def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling, rep, grads):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device")
@@ -73,12 +82,12 @@ def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling, rep):
     ge.build()
     out = str(tmp_path)
     ctx = mp.get_context("spawn")
-    single = ctx.Process(target=_run, args=(0, 1, 0, out, case, chunks, device_sampling, rep))
+    single = ctx.Process(target=_run, args=(0, 1, 0, out, case, chunks, device_sampling, rep, grads))
     single.start()
     single.join(600)
     assert single.exitcode == 0
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, device_sampling, rep)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, out, case, chunks, device_sampling, rep, grads)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -91,6 +100,10 @@ def test_world2_on_one_gpu(tmp_path, case, chunks, device_sampling, rep):
         assert np.array_equal(r0[k], r1[k]), k
     assert np.array_equal(r0["pi1"], one["pi1"])             # phi / pi do not depend on the split over ranks
     assert r0["edges"][0] == one["edges"][0] and r0["ppx"][0] == one["ppx"][0]
+    if grads != "sharded":  # the whole gradient on every rank: nothing is summed in another order
+        for k in ("pi", "theta", "beta"):
+            assert np.array_equal(r0[k], one[k]), k
+        assert r0["ppx"][1] == one["ppx"][1] or abs(r0["ppx"][1] - one["ppx"][1]) <= 1e-6 * one["ppx"][1]
     assert np.allclose(r0["theta"], one["theta"], rtol=2e-5, atol=1e-7)   # gradient summed in another association
     # pi after several iterations: same trajectory up to the rounding of beta (entries are O(1/K); tiny ones sit
     # next to the 1e-24 clamp and are compared absolutely)
