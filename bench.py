@@ -645,7 +645,9 @@ def main():
     if fallback:
         loop_note += "; %d run(s) finished on the stream-event hand-over after a device-side wait gave up" % fallback
     phi_split = None if world == 1 else dict(getattr(lrn, "calibration", {}), replicated_groups=lrn.g_rep,
-                                             groups_per_block=lrn.cc, chunks=lrn.nch)
+                                             groups_per_block=lrn.cc, chunks=lrn.nch,
+                                             beta_gradient="%s%s" % (lrn.grads_mode, " (update_pi folded into its launch)"
+                                                                     if lrn.grads_mode == "replicated" and lrn.grads_fused else ""))
     if world > 1:
         # what makes a multi-GPU line readable by itself: a traced (untimed) window right after the timed one -- per
         # non-link step where the time went (own blocks, replicated groups, each chunk's exchange and what of it was
@@ -782,7 +784,8 @@ def main():
                                    "reproduce a reference trajectory; --host-sampling does)",
                        "loop": loop_note,
                        "host": "python (ctypes -> C ABI); see cpp_dropin for the C++ mcmc::Learner",
-                       "parallelism": "replicated pi, node-sharded phi, edge-sharded beta x%d" % world,
+                       "parallelism": ("one GPU" if world == 1 else
+                                       "replicated pi, node-sharded phi x%d, beta gradient %s" % (world, phi_split["beta_gradient"])),
                        "phi_split": phi_split},
             "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
             "step_classes": r["step_classes"],

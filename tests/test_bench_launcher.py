@@ -96,7 +96,9 @@ def test_plain_bench_two_ranks_end_to_end():
     split = rec["config"]["phi_split"]
     assert split is not None and split["exchange"] in ("collective", "p2p") and 0.0 <= split["rho"] <= 1.0
     assert split["predicted_phi_speedup"] is None or split["predicted_phi_speedup"] > 0
-    assert rec["config"]["parallelism"].endswith("x2")
+    assert "node-sharded phi x2" in rec["config"]["parallelism"]
+    assert split["beta_gradient"].startswith(("replicated", "sharded")) and split["beta_gradient"] in rec["config"]["parallelism"]
+    assert "gradient" in split["trace"] or "error" in split["trace"]
     # the step trace that makes a multi-GPU line diagnosable by itself
     tr = split["trace"]
     assert "error" not in tr, tr
