@@ -70,9 +70,14 @@ def parse():
                          "one phase of the run makes no progress for this long; -1: 300 s with more than one rank (a "
                          "collective one rank never joins blocks its peers for RCCL's own 10 minutes and says nothing "
                          "about where), off with one; 0: off")
-    ap.add_argument("--settle-s", type=float, default=3.0,
-                    help="seconds of untimed iterations BEFORE the warm-up steps: the package is at its power cap under "
-                         "update_phi and its power controller oscillates for the first ~3 s of load (profiles/README.md)")
+    ap.add_argument("--sustained-s", type=float, default=3.0,
+                    help="after the timed window: this many seconds of untimed iterations, then a SECOND window of the "
+                         "same --steps, reported as `sustained` (what a long run sees once the package's power "
+                         "controller has settled; `value` stays the contract's warm-up + steps window); 0: off")
+    ap.add_argument("--settle-s", type=float, default=1.0,
+                    help="seconds of untimed iterations BEFORE the warm-up steps: the shader clock needs a few hundred "
+                         "milliseconds of load to ramp from its idle state, which --warmup 5 (a few milliseconds) does "
+                         "not give it; launches during the ramp run 2-9 %% long (profiles/README.md, round 4)")
     return ap.parse_args()
 
 
@@ -624,6 +629,7 @@ def main():
     wd.phase("Learner() incl. the split calibration's update_phi / all-gather / point-to-point timings")
     lrn = Learner(cfg, ds, rank=rank, world_size=world)
     setup_s = time.perf_counter() - t_setup
+    pi_placement = getattr(lrn, "pi_placement", None)
     lrn_E, lrn_H = int(ds.E), int(ds.heldout_edges.size)
     graphs = lrn.loop is not None
     note("learner ready (%s loop)" % ("device-descriptor" if graphs else "eager"))
@@ -631,6 +637,25 @@ def main():
     r = measure(args, lrn, cfg, m, args.steps, args.warmup, world, dist, torch, args.workload, args.ppx_calls,
                 settle_s=args.settle_s)
     dt, edges_done, roofline = r["dt"], r["edges_done"], r["roofline"]
+
+    # ---- the same window again after --sustained-s seconds of load: update_phi holds the package at its power cap, and
+    # what the chip delivers once its power controller has settled is what a long run sees (profiles/README.md)
+    sustained = None
+    if args.sustained_s > 0:
+        try:
+            r2 = measure(args, lrn, cfg, m, args.steps, 0, world, dist, torch, args.workload, 0, settle_s=args.sustained_s)
+            rf2 = r2["roofline"] or {}
+            sustained = {"after_s": args.sustained_s, "untimed_steps": r2["settle_steps"], "steps": args.steps,
+                         "value": r2["value"], "unit": "edges/s", "ms_per_step": r2["ms_per_step"],
+                         "value_per_class": (r2["value_per_class"] or {}).get("value"),
+                         "step_classes": r2["step_classes"],
+                         "update_phi_ms": rf2.get("avg_launch_ms"), "frac": rf2.get("frac"),
+                         "device_state": r2["device_state"],
+                         "what": "a second window of the same --steps after that many seconds of untimed iterations: the "
+                                 "throughput once the package's power controller has settled under this load (`value` "
+                                 "above is the contract's window: --warmup steps after start-up, then --steps)"}
+        except Exception as e:  # a reported extra: never lose the line over it
+            sustained = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -800,9 +825,11 @@ def main():
             "reference_default_wg": ref_wg,
             "small_configs": small,
             "large_configs": large,
+            "sustained": sustained,
+            "pi_placement": pi_placement,
             "settle": {"seconds": args.settle_s, "steps": r.get("settle_steps", 0),
-                       "why": "untimed iterations in front of the warm-up steps: update_phi holds the package at its power "
-                              "cap and the power controller oscillates by +-4 % for the first ~3 s of load (profiles/README.md)"},
+                       "why": "untimed iterations in front of the warm-up steps: the clocks' ramp from idle (a few hundred "
+                              "milliseconds) is not part of the measurement; `sustained` is the window after seconds of load"},
             "cpp_dropin": cpp,
         }
         wd.phase("done")

@@ -111,6 +111,10 @@ struct Config {
   // "replicated" (every rank the whole gradient: no collective, theta bit-identical to one GPU's), -1 = auto:
   // replicated where update_pi can be folded into the gradient launch (device-sampled Node mini-batches, K <= 1024)
   int beta_grads;
+  // new: where pi lands in HBM moves update_phi's launch time by up to 10 % (profiles/README.md, round 4): at start-up
+  // this many allocations of pi are timed under update_phi and the fastest is kept (only when pi is >= 1 GB and the
+  // candidates fit in a third of the free HBM; 0 or 1: off; AMMSB_PI_CANDIDATES overrides)
+  uint32_t pi_placement_candidates;
 
   Config();
 };

@@ -109,6 +109,7 @@ class Learner {
   uint32_t cc_ = 0, g_rep_ = 0, nch_ = 1;
   void SetSplit(uint32_t g_rep);
   void CalibrateSplit();              // Config::phi_replicate < 0: balance recomputing a group against receiving it
+  void PlacePi();                     // Config::pi_placement_candidates: keep the allocation of pi update_phi runs fastest over
   void* xstream_ = nullptr;           // the exchanges of a step run here, beside the next block's update_phi
   void* ev_block_ = nullptr;          // main stream: a block's update_phi has been enqueued (the exchange waits for it)
   void* ev_xdone_ = nullptr;          // exchange stream: the step's exchanges are done (the main stream waits for it)

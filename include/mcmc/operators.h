@@ -39,6 +39,9 @@ class RowPartitionedMatrix {
   uint32_t RowsPerBlock() const { return rows_per_alloc_; }
   std::vector<clcuda::Buffer<T>>& Blocks() { return blocks_; }
   const ammsb_rpm& Get() const { return desc_; }
+  // Exchange storage with `other` (same shape): every holder of a pointer to this matrix then works on other's blocks
+  // (Learner::PlacePi keeps the allocation of pi that update_phi runs fastest over).
+  void SwapStorage(RowPartitionedMatrix& other);
 
  private:
   clcuda::Queue queue_;

@@ -64,6 +64,14 @@ RowPartitionedMatrix<T>::RowPartitionedMatrix(clcuda::Queue queue, uint32_t rows
   desc_.num_cols = cols_;
   desc_.num_blocks = static_cast<uint32_t>(blocks_.size());
 }
+template <class T>
+void RowPartitionedMatrix<T>::SwapStorage(RowPartitionedMatrix<T>& other) {
+  if (rows_ != other.rows_ || cols_ != other.cols_ || rows_per_alloc_ != other.rows_per_alloc_)
+    throw std::invalid_argument("RowPartitionedMatrix::SwapStorage: shapes differ");
+  blocks_.swap(other.blocks_);
+  std::swap(desc_, other.desc_);
+}
+
 template class RowPartitionedMatrix<Float>;
 template class RowPartitionedMatrix<uint32_t>;
 

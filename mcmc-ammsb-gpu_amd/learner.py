@@ -27,6 +27,7 @@ cuckoo sets are replicated; the mini-batch is the same on every rank (same seeds
     ppx    contiguous slices of the held-out edges; 4 scalars per rank are all-gathered.
 """
 import concurrent.futures
+import os
 import time
 
 import numpy as np
@@ -88,6 +89,11 @@ class Config:
                                                      # mini-batch has a few dozen edges: the all-gather of the partial
                                                      # sums would cost more than the gradient, and the result is then
                                                      # the single-GPU one bit for bit)
+        self.pi_placement_candidates = 6             # (new) where pi lands in HBM moves update_phi's launch time by up to
+                                                     # 10 % (profiles/README.md, round 4): at start-up this many
+                                                     # allocations of pi are timed under update_phi and the fastest
+                                                     # is kept (only when pi is >= 1 GB and the candidates fit in a
+                                                     # third of the free HBM; 0 or 1: off; AMMSB_PI_CANDIDATES overrides)
         self.force_exchange = False                  # (new, tests) take the multi-rank code path even with one rank
         # (new) whole iterations as captured hipGraphs (include/ammsb.h ammsb_loop): "auto" = whenever it applies
         # (device sampling, one rank); False keeps the eager launch-by-launch loop (the parity form); results are
@@ -261,6 +267,8 @@ class Learner:
         self.theta.copy_(c.from_numpy(hostlib.theta_init(K, cfg.eta0, cfg.eta1)))
         ops.beta_from_theta(c, self.theta, self.beta)
         ops.RandomGammaAndNormalize(c, cfg.eta0, cfg.eta1, self.pi, self.phi)
+        self.pi_placement = None
+        self._place_pi()
         ops.synchronize()
         if self.sharded and cfg.phi_replicate == "auto":
             self._calibrate_split()
@@ -325,6 +333,70 @@ class Learner:
     def _dist(self):
         import torch.distributed as dist
         return dist
+
+    # ------------------------------------------------------------------ where pi lands in HBM
+
+    def _place_pi(self):
+        """update_phi gathers 4 KiB rows of pi at random, and what the memory system delivers for that depends on
+        WHERE the table sits: the same launch over copies of pi allocated one after the other in one process differs
+        by up to 10 %, stably per allocation (tools/placement_phi.py, profiles/r04_placement_phi.txt) -- the
+        "per-process level" of update_phi's launch time.  So, once pi is initialised: copy it into a few more
+        allocations, time full-size update_phi launches over each (warm clocks first, then round-robin, so that
+        anything time-dependent hits all alike), keep the fastest, release the rest.  Results do not depend on it
+        (every candidate holds the same pi; the streams and the call counter are restored).  Every rank of a
+        multi-GPU job places its own replica."""
+        ops, cfg, phi = self.ops, self.cfg, self.phiUpdater
+        want = int(os.environ.get("AMMSB_PI_CANDIDATES", getattr(cfg, "pi_placement_candidates", 0)) or 0)
+        if want < 2 or not hasattr(ops, "elapsed_ms") or len(self.pi.blocks) != 1:
+            return
+        nbytes = 4 * cfg.N * cfg.K
+        free = torch.cuda.mem_get_info(self.ctx.device)[0]
+        if nbytes < (1 << 30):
+            return  # a table of this size is a cache matter, not an HBM-placement one
+        want = min(want, 1 + int(free // 3 // nbytes))  # the extra candidates take at most a third of the free memory
+        if want < 2:
+            self.pi_placement = {"candidates": 1, "why": "pi is %.0f GB: no room for a second candidate" % (nbytes / 1e9)}
+            return
+        c = self.ctx
+        n_nodes = min(self.samples[0].max_nodes, MAX_GROUPS)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        nodes = c.from_numpy(torch.randperm(cfg.N, generator=gen)[:n_nodes].numpy().astype(np.uint32))
+        nbrs = c.from_numpy(torch.randint(0, cfg.N, (n_nodes, cfg.num_node_sample), generator=gen).numpy().astype(np.uint32))
+        keep, calls = phi.rand.seeds.clone(), phi.count_calls
+        phi.count_calls = 1
+        cands = [self.pi] + [ops.RowPartitionedMatrix(c, cfg.N, cfg.K) for _ in range(want - 1)]
+        for p in cands[1:]:
+            p.blocks[0].copy_(self.pi.blocks[0])  # the initialised pi: whichever candidate is kept holds it
+        mine = phi.pi
+        times = [[] for _ in cands]
+
+        def three(p):
+            phi.pi = p
+            for _ in range(3):
+                phi.update_phi(nodes, nbrs, n_nodes)
+        try:
+            # clocks first: a launch right after idle runs 10-20 % long and tells candidates apart badly
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.4:
+                for p in cands:
+                    three(p)
+                ops.synchronize()
+            for rnd in range(3):  # round-robin: anything time-dependent hits all candidates alike
+                for i, p in enumerate(cands):
+                    times[i].append(ops.elapsed_ms(lambda: three(p)) / 3.0)
+        finally:
+            phi.pi = mine
+            phi.rand.seeds.copy_(keep)
+            phi.count_calls = calls
+        med = [float(np.median(t)) for t in times]
+        best = int(np.argmin(med))
+        if best != 0:
+            self.pi.adopt(cands[best])  # the objects holding self.pi see the new blocks; the first candidate is released
+        self.pi_placement = {"candidates": len(cands), "update_phi_ms": [round(x, 4) for x in med], "kept": best,
+                             "first_allocation_ms": round(med[0], 4), "kept_ms": round(med[best], 4)}
+        del cands, p
+        ops.synchronize()
+        torch.cuda.empty_cache()
 
     def _set_split(self, g_rep):
         """Fix the ownership map: groups [0, g_rep) replicated, the rest in R * chunks blocks of cc groups."""

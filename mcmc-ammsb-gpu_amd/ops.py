@@ -262,6 +262,12 @@ class RowPartitionedMatrix:
         self.desc.num_cols = self.cols
         self.desc.num_blocks = len(self.blocks)
 
+    def adopt(self, other):
+        """Take over `other`'s storage (same shape): every holder of this object then works on the new blocks."""
+        if (other.rows, other.cols, other.rows_in_block) != (self.rows, self.cols, self.rows_in_block):
+            raise AmmsbError("adopt: shapes differ")
+        self.blocks, self.desc = other.blocks, other.desc
+
     def Rows(self):
         return self.rows
 

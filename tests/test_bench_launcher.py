@@ -86,13 +86,15 @@ def test_plain_bench_two_ranks_end_to_end():
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "C1", "--steps", "30", "--warmup", "5",
-                          "--no-cpu-baseline", "--cpp-dropin", "0"], env=env, capture_output=True, text=True, timeout=900)
+                          "--no-cpu-baseline", "--cpp-dropin", "0", "--sustained-s", "0.5"], env=env, capture_output=True,
+                         text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 0 and "REHEARSAL" in rec["data"]
     assert rec["steps"] == 30 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["sustained"]["value"] > 0 and rec["sustained"]["untimed_steps"] > 0  # the second window, on every rank
     split = rec["config"]["phi_split"]
     assert split is not None and split["exchange"] in ("collective", "p2p") and 0.0 <= split["rho"] <= 1.0
     assert split["predicted_phi_speedup"] is None or split["predicted_phi_speedup"] > 0
@@ -116,6 +118,7 @@ def test_single_gpu_line_carries_device_state_and_settle():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, BENCH, "--workload", "C1", "--steps", "200", "--warmup", "20", "--settle-s", "0.2",
+                          "--sustained-s", "0.3",
                           "--no-cpu-baseline", "--cpp-dropin", "0", "--extras", "0"], env=env, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -124,6 +127,9 @@ def test_single_gpu_line_carries_device_state_and_settle():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["steps"] == 200 and rec["value"] > 0 and rec["dtype"] == "f32"
     assert rec["settle"]["steps"] > 0 and rec["settle"]["seconds"] == 0.2
+    su = rec["sustained"]  # the window after seconds of load, beside the contract's
+    assert su["after_s"] == 0.3 and su["untimed_steps"] > 0 and su["value"] > 0 and su["steps"] == 200
+    assert su["device_state"]["power_w"][0] > 0
     ds = rec["roofline"]["device_state"]
     assert ds["compute_partition"] and ds["memory_partition"]
     assert len(ds["sclk_mhz"]) == 2 and len(ds["power_w"]) == 2 and ds["power_cap_w"][0] > 0
