@@ -74,10 +74,12 @@ def parse():
                     help="after the timed window: this many seconds of untimed iterations, then a SECOND window of the "
                          "same --steps, reported as `sustained` (what a long run sees once the package's power "
                          "controller has settled; `value` stays the contract's warm-up + steps window); 0: off")
-    ap.add_argument("--settle-s", type=float, default=1.0,
-                    help="seconds of untimed iterations BEFORE the warm-up steps: the shader clock needs a few hundred "
-                         "milliseconds of load to ramp from its idle state, which --warmup 5 (a few milliseconds) does "
-                         "not give it; launches during the ramp run 2-9 %% long (profiles/README.md, round 4)")
+    ap.add_argument("--settle-s", type=float, default=-8.0,
+                    help="untimed iterations BEFORE the warm-up steps.  > 0: that many seconds.  < 0 (default -8): until "
+                         "update_phi's launch time and the reported package power have stopped moving, at least 1 s, at most "
+                         "that many seconds -- the clocks' ramp from idle and, on some boxes, several seconds in which the "
+                         "power controller holds a higher shader clock and the launch runs 8 %% longer are start-up, not "
+                         "the measurement (profiles/README.md, round 4).  0: off")
     return ap.parse_args()
 
 
@@ -332,22 +334,57 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
     # ---- settle: untimed iterations until the package's power controller has reached its steady state (the same
     # number of steps on every rank: decided by rank 0's clock, in whole chunks)
     phase = getattr(args, "phase", lambda name: None)
-    settle_steps = 0
-    if settle_s > 0:
+    settle_steps, settle_log = 0, None
+    if settle_s != 0:
+        # settle_s > 0: that many seconds.  settle_s < 0 ("auto"): until the package is in its steady state under this
+        # load -- update_phi's launch time (device stamps) and the power the driver reports have both stopped moving
+        # (five consecutive chunks within 1 % / 3 %), at least 1 s, at most -settle_s seconds.  On some boxes that is
+        # immediate, on others the first seconds of load run 8 % slower at a HIGHER shader clock until the power
+        # controller has found its state (profiles/README.md, round 4).
         phase("%s: settle iterations" % workload)
-        chunk = 100 if m >= 32768 else 2000
+        chunk = 100 if m >= 32768 else (2000 if world == 1 else 200)
         t_s = time.perf_counter()
+        hist = []
+        dev_i = torch.cuda.current_device()
         while True:
+            first_s = lrn.phiUpdater.count_calls + 1
+            if settle_s < 0:
+                lrn.step_log = []
             lrn.Run(chunk)
             sync()
             settle_steps += chunk
-            go = time.perf_counter() - t_s < settle_s and settle_steps < 20000
+            t_now = time.perf_counter() - t_s
+            if settle_s > 0:
+                go = t_now < settle_s and settle_steps < 20000
+            else:
+                phi_ms = None
+                if lrn.loop is not None:
+                    try:
+                        st_s = lrn.loop.step_stamps(first_s, chunk)
+                        non = np.concatenate(lrn.step_log) == m
+                        if non.any():
+                            phi_ms = float((st_s[non, 1] - st_s[non, 0]).mean() * 1e-6)
+                    except Exception:
+                        phi_ms = None
+                lrn.step_log = None
+                hist.append((round(t_now, 2), phi_ms, gpu_state.read(dev_i).get("power_w")))
+                last = hist[-5:]
+
+                def steady(vals, tol):
+                    vals = [v for v in vals if v]
+                    return len(vals) < 5 or (max(vals) - min(vals)) <= tol * max(vals)
+                stable = len(hist) >= 5 and steady([h[1] for h in last], 0.01) and steady([h[2] for h in last], 0.03)
+                go = (t_now < 1.0 or not stable) and t_now < -settle_s and settle_steps < 40000
             if world > 1:
                 flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
                 dist.broadcast(flag, 0)
                 go = bool(flag.item())
             if not go:
                 break
+        if settle_s < 0:
+            settle_log = {"seconds": round(time.perf_counter() - t_s, 2),
+                          "update_phi_ms_first_last": [next((h[1] for h in hist if h[1]), None), hist[-1][1]],
+                          "power_w_first_last": [hist[0][2], hist[-1][2]], "chunks": len(hist)}
 
     # ---- perplexity latency (mean of ppx_calls, after one untimed call)
     ppx, ppx_ms = None, None
@@ -547,7 +584,7 @@ def measure(args, lrn, cfg, m, steps, warmup, world, dist, torch, workload, ppx_
         device_state["shader_clock_how"] = "probe failed: %r" % (e,)
     if roofline is not None:
         roofline["device_state"] = device_state
-    return {"settle_steps": settle_steps, "device_state": device_state,
+    return {"settle_steps": settle_steps, "settle_log": settle_log, "device_state": device_state,
             "value": edges_done / dt, "ms_per_step": dt * 1e3 / steps, "dt": dt, "edges_done": int(edges_done),
             "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "step_classes": step_classes,
             "value_per_class": value_per_class, "roofline": roofline, "ppx_ms": ppx_ms, "ppx": ppx,
@@ -706,7 +743,8 @@ def main():
             cfg32 = make_cfg(K, m, n, 32, 32, 32, use_graph)
             l32 = Learner(cfg32, ds, rank=0, world_size=1)
             st32 = max(10, min(args.steps, 40))
-            r32 = measure(args, l32, cfg32, m, st32, min(args.warmup, 5), 1, dist, torch, args.workload, 2)
+            r32 = measure(args, l32, cfg32, m, st32, min(args.warmup, 5), 1, dist, torch, args.workload, 2,
+                          settle_s=args.settle_s)
             ref_wg = sub_record(r32, cfg32, st32, min(args.warmup, 5), loop_form(l32.loop is not None))
             ref_wg["what"] = ("%s with --phi-wg / --beta-wg / --ppx-wg left at the reference's defaults (32, main.cc:61-64): "
                               "%d columns per work-item" % (args.workload, (K + 31) // 32))
@@ -827,7 +865,7 @@ def main():
             "large_configs": large,
             "sustained": sustained,
             "pi_placement": pi_placement,
-            "settle": {"seconds": args.settle_s, "steps": r.get("settle_steps", 0),
+            "settle": {"seconds": args.settle_s, "steps": r.get("settle_steps", 0), "auto": r.get("settle_log"),
                        "why": "untimed iterations in front of the warm-up steps: the clocks' ramp from idle (a few hundred "
                               "milliseconds) is not part of the measurement; `sustained` is the window after seconds of load"},
             "cpp_dropin": cpp,

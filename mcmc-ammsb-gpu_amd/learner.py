@@ -89,7 +89,7 @@ class Config:
                                                      # mini-batch has a few dozen edges: the all-gather of the partial
                                                      # sums would cost more than the gradient, and the result is then
                                                      # the single-GPU one bit for bit)
-        self.pi_placement_candidates = 6             # (new) where pi lands in HBM moves update_phi's launch time by up to
+        self.pi_placement_candidates = 10            # (new) where pi lands in HBM moves update_phi's launch time by up to
                                                      # 10 % (profiles/README.md, round 4): at start-up this many
                                                      # allocations of pi are timed under update_phi and the fastest
                                                      # is kept (only when pi is >= 1 GB and the candidates fit in a
@@ -358,6 +358,7 @@ class Learner:
             self.pi_placement = {"candidates": 1, "why": "pi is %.0f GB: no room for a second candidate" % (nbytes / 1e9)}
             return
         c = self.ctx
+        t_begin = time.perf_counter()
         n_nodes = min(self.samples[0].max_nodes, MAX_GROUPS)
         gen = torch.Generator(device="cpu").manual_seed(7)
         nodes = c.from_numpy(torch.randperm(cfg.N, generator=gen)[:n_nodes].numpy().astype(np.uint32))
@@ -397,6 +398,7 @@ class Learner:
         del cands, p
         ops.synchronize()
         torch.cuda.empty_cache()
+        self.pi_placement["seconds"] = round(time.perf_counter() - t_begin, 2)
 
     def _set_split(self, g_rep):
         """Fix the ownership map: groups [0, g_rep) replicated, the rest in R * chunks blocks of cc groups."""
