@@ -431,8 +431,24 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
       return AMMSB_EHIP;                                                                           \
     }                                                                                              \
   } while (0)
-  CREATE_HIP(hipStreamCreateWithFlags(&lp->main, hipStreamNonBlocking));
-  CREATE_HIP(hipStreamCreateWithFlags(&lp->side, hipStreamNonBlocking));
+  {
+    // AMMSB_LOOP_PRIO=1 (A/B runs): the main chain on the highest stream priority, the sampling chain on the lowest --
+    // the sampling kernels of mini-batch i + 2 run beside update_phi of step i and cost it ~6 % (1.51 ms alone against
+    // 1.60 in the loop at C3); they have two steps' time to finish in
+    static const int prio = [] {
+      const char* f = getenv("AMMSB_LOOP_PRIO");
+      return f ? atoi(f) : 0;
+    }();
+    int least = 0, greatest = 0;
+    if (prio) CREATE_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (prio && least != greatest) {
+      CREATE_HIP(hipStreamCreateWithPriority(&lp->main, hipStreamNonBlocking, greatest));
+      CREATE_HIP(hipStreamCreateWithPriority(&lp->side, hipStreamNonBlocking, least));
+    } else {
+      CREATE_HIP(hipStreamCreateWithFlags(&lp->main, hipStreamNonBlocking));
+      CREATE_HIP(hipStreamCreateWithFlags(&lp->side, hipStreamNonBlocking));
+    }
+  }
   for (hipEvent_t* ev : {&lp->ev_in, &lp->ev_out, &lp->ev_prime, &lp->ev_first, &lp->ev_main[0], &lp->ev_main[1],
                          &lp->ev_main[2], &lp->ev_samp[0], &lp->ev_samp[1], &lp->ev_samp[2]})
     CREATE_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
