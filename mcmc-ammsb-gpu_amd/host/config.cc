@@ -56,7 +56,7 @@ Config::Config() {  // config.h:69-101
   phi_replicate = -1;
   beta_shard_min_edges = 4096;
   beta_grads = -1;
-  pi_placement_candidates = 10;
+  pi_placement_candidates = 12;
 }
 
 std::ostream& operator<<(std::ostream& out, const ulong2& v) { return out << v[0] << "," << v[1]; }

@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
       Opt("loop-timers", 0, &cfg.loop_timers, "1 (new: per-kernel device times in PrintStats under --async / --graph)"),
       Opt("phi-chunks", 0, &cfg.phi_chunks, "4 (new, with --exchange: blocks per rank whose exchange overlaps the next block's update_phi)"),
       Opt("phi-replicate", 0, &cfg.phi_replicate, "-1 (new, with --exchange: fraction of the virtual groups every rank computes itself; < 0 = measured at start-up)"),
-      Opt("pi-candidates", 0, &cfg.pi_placement_candidates, "10 (new: allocations of pi timed under update_phi at start-up, the fastest kept; 0 = off)"),
+      Opt("pi-candidates", 0, &cfg.pi_placement_candidates, "12 (new: allocations of pi timed under update_phi at start-up, the fastest kept; 0 = off)"),
       Opt("beta-grads", 0, &cfg.beta_grads, "-1 (new, with --exchange: 0 = gradient cut over the ranks + all-gather, 1 = every rank the whole gradient, -1 = 1 where update_pi folds into its launch)"),
       Opt("beta-shard-min-edges", 0, &cfg.beta_shard_min_edges, "4096 (new, with --exchange: mini-batches of at most this many edges keep their whole gradient on every rank)"),
       OptStr("exchange", 0, &exchangeKind),  // (new) rccl | host: one process per GPU, RANK / WORLD_SIZE / MASTER_* from the env

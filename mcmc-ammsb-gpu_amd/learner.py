@@ -89,7 +89,7 @@ class Config:
                                                      # mini-batch has a few dozen edges: the all-gather of the partial
                                                      # sums would cost more than the gradient, and the result is then
                                                      # the single-GPU one bit for bit)
-        self.pi_placement_candidates = 10            # (new) where pi lands in HBM moves update_phi's launch time by up to
+        self.pi_placement_candidates = 12            # (new) where pi lands in HBM moves update_phi's launch time by up to
                                                      # 10 % (profiles/README.md, round 4): at start-up this many
                                                      # allocations of pi are timed under update_phi and the fastest
                                                      # is kept (only when pi is >= 1 GB and the candidates fit in a
