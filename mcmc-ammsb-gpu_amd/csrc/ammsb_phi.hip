@@ -2528,6 +2528,16 @@ inline int pick_kpt(uint64_t K, uint32_t L) {
     default: return AMMSB_EINVAL;                                     \
   }
 
+// In-process A/B of the K = 1024 kernel forms (tools/phi_forms_ab.py): -1 = follow the environment switches.  A form
+// comparison across PROCESSES measures where pi landed (DESIGN_HISTORY.md R4.7), not the kernels.
+static int g_phi_form_lds3 = -1, g_phi_form_nb = -1, g_phi_form_ring = -1;
+extern "C" int ammsb_debug_phi_forms(int lds3, int nb, int ring) {
+  g_phi_form_lds3 = lds3;
+  g_phi_form_nb = nb;
+  g_phi_form_ring = ring;
+  return AMMSB_OK;
+}
+
 static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm* pi, const float* phi_sum,
                              const ammsb_set* training_set, const uint32_t* nodes, const uint32_t* neighbors,
                              uint32_t n_nodes, uint32_t step_count, ammsb_seed* seeds, uint32_t wg, uint32_t flags,
@@ -2593,10 +2603,11 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   const uint32_t n_groups = a.group_end - a.group_begin;
   hipStream_t s = as_stream(stream);
   // AMMSB_PHI_LDS3=0|1: the three-slot K = 1024 kernel (update_phi_lds3_kernel) off / on (A/B runs; default below)
-  static const bool lds3 = [] {
+  static const bool lds3_env = [] {
     const char* f = getenv("AMMSB_PHI_LDS3");
     return f ? atoi(f) != 0 : AMMSB_PHI_LDS3_DEFAULT;
   }();
+  const bool lds3 = g_phi_form_lds3 >= 0 ? g_phi_form_lds3 != 0 : lds3_env;  // (ammsb_debug_phi_forms: in-process A/B)
   static const bool force_reg = [] {
     const char* f = getenv("AMMSB_PHI_FORM");
     return f && f[0] == 'r';
@@ -2679,10 +2690,11 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
   // LDS-streamed kernels: K == wg * kpt exactly.  One wave per node up to K = 2048 (wg 64); for longer rows the
   // node is spread over wg / 64 waves with 16 columns per lane (K = 4096: wg 256, K = 8192: wg 512, ...).
   if (!force_reg && p.K == (uint64_t)wg * kpt && pi->num_cols % 4 == 0 && a.n * sizeof(uint32_t) <= 8192) {
-    static const int ring = [] {  // AMMSB_PHI_RING=2|4|8: ring depth of the short-row kernels (A/B runs)
+    static const int ring_env = [] {  // AMMSB_PHI_RING=2|4|8: ring depth of the short-row kernels (A/B runs)
       const char* f = getenv("AMMSB_PHI_RING");
       return f ? atoi(f) : 0;
     }();
+    const int ring = g_phi_form_ring >= 0 ? g_phi_form_ring : ring_env;
     // (tried: rings deep enough to hold all of a node's rows -- <4, 32, 4>, <16, 1, 8> -- for launches of a few dozen
     // nodes, i.e. link mini-batches, where the chip is empty: the kernels got slower, 18.8 -> 22.0 us at K = 256 and
     // 50.4 -> 54.4 us at K = 1024 (kernel trace).  A lone wave is not waiting for rows: it is the dependent-instruction
@@ -2704,10 +2716,11 @@ static int update_phi_common(ammsb_ctx* ctx, const float* beta, const ammsb_rpm*
           if (ring == 4 || (a.n & 1)) return launch_phi_lds<8, 1, 4>(ctx, a, n_groups, s);
           return launch_phi_lds2<8, 4, 2>(ctx, a, n_groups, s);
         case 16: {
-          static const int nb = [] {  // AMMSB_PHI_NB=1|2: nodes per block of the K = 1024 kernel (A/B runs)
+          static const int nb_env = [] {  // AMMSB_PHI_NB=1|2: nodes per block of the K = 1024 kernel (A/B runs)
             const char* f = getenv("AMMSB_PHI_NB");
             return f ? atoi(f) : 1;
           }();
+          const int nb = g_phi_form_nb >= 0 ? g_phi_form_nb : nb_env;
           if (nb == 2) return launch_phi_lds<16, 1, 2, 2>(ctx, a, n_groups, s);
           // A/B: three rows in flight, 8 waves per CU -- C3 update_phi 1.76 -> 2.04 ms (profiles/r03_c3_ring_ab.log)
           if (ring == 4) return launch_phi_lds<16, 1, 4>(ctx, a, n_groups, s);
