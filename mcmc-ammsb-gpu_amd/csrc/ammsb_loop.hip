@@ -441,7 +441,17 @@ extern "C" int ammsb_loop_create(ammsb_ctx* ctx, const ammsb_loop_config* cfg, a
     }();
     int least = 0, greatest = 0;
     if (prio) CREATE_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    if (prio && least != greatest) {
+    // AMMSB_LOOP_SIDE_CUS=n (A/B runs): the sampling chain confined to n of the device's CUs (a CU mask on its stream)
+    static const int side_cus = [] {
+      const char* f = getenv("AMMSB_LOOP_SIDE_CUS");
+      return f ? atoi(f) : 0;
+    }();
+    if (side_cus > 0 && side_cus < ctx->num_cus) {
+      uint32_t mask[16] = {0};
+      for (int i = 0; i < side_cus && i < 512; ++i) mask[i / 32] |= 1u << (i % 32);
+      CREATE_HIP(hipStreamCreateWithFlags(&lp->main, hipStreamNonBlocking));
+      CREATE_HIP(hipExtStreamCreateWithCUMask(&lp->side, (uint32_t)((ctx->num_cus + 31) / 32), mask));
+    } else if (prio && least != greatest) {
       CREATE_HIP(hipStreamCreateWithPriority(&lp->main, hipStreamNonBlocking, greatest));
       CREATE_HIP(hipStreamCreateWithPriority(&lp->side, hipStreamNonBlocking, least));
     } else {
