@@ -254,7 +254,7 @@ def cpp_dropin(args, hostlib, N, K, m, n, wg, edges, note):
     with tempfile.TemporaryDirectory() as d:
         f = os.path.join(d, "g.bin.gz")
         hostlib.dump_dataset(f, N, 0.01, edges)
-        iters = max(args.steps, 200)
+        iters = max(args.steps, 1000)  # ~1 s per form: past the clocks' ramp from idle
         for name, flags in (("graph", ["--async", "1", "--graph", "1"]), ("async", ["--async", "1"]), ("sync", [])):
             cmd = [exe, "--load-data", "1", "--load-file", f, "-k", str(K), "-m", str(m), "-n", str(n), "-x", str(iters),
                    "-i", str(iters), "--phi-wg", str(wg), "--beta-wg", str(wg), "--ppx-wg", str(wg),
