@@ -60,6 +60,7 @@ struct BetaArgs {
   float epsilon;
   const ammsb_step_desc* desc;  // non-null (captured graph): edges [0, desc->n_edges), P = min(n_edges, P)
   ammsb_pi_fusion fuse;         // update_pi folded in (LDS kernels at wg 64, with a descriptor): see ammsb_step.h
+  uint32_t pi_nt;               // (fused LDS kernels) the pi rows are stored with the non-temporal hint
   unsigned long long* stamps;   // optional (with desc): block 0 notes the device time at which it starts
 };
 
@@ -753,10 +754,25 @@ __device__ __forceinline__ void beta_grads_lds_body(const BetaArgs& a) {
       const float sum = VLn::tree(partial);
       float* dst = rpm_row(a.pi, partner);
 #pragma unroll
-      for (int p = 0; p < HP; ++p) {
-        pbn[p] = f32x2{pbn[p].x / sum, pbn[p].y / sum};
-        dst[tid + 2 * L * p] = pbn[p].x;
-        dst[tid + 2 * L * p + L] = pbn[p].y;
+      for (int p = 0; p < HP; ++p) pbn[p] = f32x2{pbn[p].x / sum, pbn[p].y / sum};
+      // Non-temporal stores (AMMSB_BETA_PI_NT=1, off by default): the 268 MB of rows a C3 launch writes are not read
+      // again before the next update_phi (the gradient takes them from registers), and left in the caches they are
+      // written back UNDER that launch -- in one process, over one pi, update_phi runs 2-6 % longer after this kernel
+      // than after separate update_pi + gradient launches.  With the hint it recovers half of that and this kernel
+      // loses as much: whole step 1.7745 (plain) / 1.7825 (nt) / 1.8187 ms (separate launches) on one box
+      // (tools/phi_in_sequence.py, profiles/r04_phi_in_sequence.txt).  (wave-uniform branch)
+      if (a.pi_nt) {
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          __builtin_nontemporal_store(pbn[p].x, dst + tid + 2 * L * p);
+          __builtin_nontemporal_store(pbn[p].y, dst + tid + 2 * L * p + L);
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          dst[tid + 2 * L * p] = pbn[p].x;
+          dst[tid + 2 * L * p + L] = pbn[p].y;
+        }
       }
       if (tid == 0) a.fuse.phi_sum[partner] = sum;
     } else if (u != cur_u) {
@@ -1368,6 +1384,15 @@ bool ammsb_beta_can_fuse_pi(ammsb_ctx* ctx, uint32_t phi_wg, uint32_t beta_wg) {
   return ctx && phi_wg == beta_wg && beta_fuse_shape(ctx, beta_wg);
 }
 
+#ifndef AMMSB_BETA_PI_NT_DEFAULT
+#define AMMSB_BETA_PI_NT_DEFAULT 0
+#endif
+static int g_beta_pi_nt = -1;  // in-process A/B (tools/phi_in_sequence.py): -1 = follow AMMSB_BETA_PI_NT
+extern "C" int ammsb_debug_beta_pi_nt(int on) {
+  g_beta_pi_nt = on;
+  return AMMSB_OK;
+}
+
 static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* beta, const ammsb_rpm* pi,
                              const ammsb_set* training_set, const uint64_t* edges, uint32_t n_edges,
                              uint32_t edge_begin, uint32_t edge_end, uint32_t wg, float* grads_out,
@@ -1421,6 +1446,15 @@ static int beta_grads_common(ammsb_ctx* ctx, const float* theta, const float* be
   a.desc = desc;
   a.stamps = desc ? stamps : nullptr;
   a.fuse = ammsb_pi_fusion{nullptr, nullptr, nullptr, nullptr};
+  {
+    static const int nt_env = [] {  // AMMSB_BETA_PI_NT=0|1 (A/B runs)
+      const char* f = getenv("AMMSB_BETA_PI_NT");
+      return f ? atoi(f) : AMMSB_BETA_PI_NT_DEFAULT;
+    }();
+    const uint64_t pi_bytes = pi->num_rows * pi->num_cols * sizeof(float);
+    // (a pi that fits the 256 MB Infinity Cache is re-read from there: keep its rows cached, as update_phi's hint does)
+    a.pi_nt = (g_beta_pi_nt >= 0 ? g_beta_pi_nt : nt_env) != 0 && pi_bytes > (256ull << 20) ? 1u : 0u;
+  }
   if (fuse && fuse->phi_vec) {
     // (the slots of a fused launch write every pi row of the mini-batch exactly once: only over the whole batch)
     AMMSB_CHECK_ARG(ctx, fuse->phi_sum && fuse->nodes && beta_fuse_shape(ctx, wg) && (desc || (edge_begin == 0 && edge_end == n_edges)),

@@ -8,8 +8,9 @@ how many memory instructions were issued after the request it waits for -- per t
 and phi_sum).  If the compiler ever merged, split, duplicated or dropped one of those stores the count would be off
 and a row would be read from LDS before it has landed -- silently.  This script disassembles the gfx950
 code object of ammsb_beta.o and requires, for every fused instantiation, that the trip loop (the innermost backward
-branch that contains both an LDS-DMA load and a store) holds exactly PIECES `global_load_lds_dwordx4` and exactly
-ST `global_store_dword`.  Run by csrc/Makefile after ammsb_beta.o is built; exits non-zero on a mismatch.
+branch that contains both an LDS-DMA load and a store) holds exactly PIECES `global_load_lds_dwordx4` and executes
+exactly ST `global_store_dword` per trip (the pi-row stores come as non-temporal / plain twins behind a wave-uniform
+branch: a pair counts once).  Run by csrc/Makefile after ammsb_beta.o is built; exits non-zero on a mismatch.
 
     python3 tools/check_fused_stores.py mcmc-ammsb-gpu_amd/csrc/ammsb_beta.o
 """
@@ -92,12 +93,19 @@ def main():
             continue
         body = insts[loop[0]:loop[1] + 1]
         loads = sum(1 for _, o, _ in body if o.startswith("global_load_lds"))
-        stores = [o for _, o, _ in body if o.startswith("global_store")]
-        wide = [o for o in stores if o != "global_store_dword"]
+        stores = [(o, a) for _, o, a in body if o.startswith("global_store")]
+        wide = [o for o, _ in stores if o != "global_store_dword"]
+        # the pi-row stores exist twice, once with the non-temporal hint and once without, behind a wave-uniform branch
+        # (BetaArgs.pi_nt): a trip EXECUTES one of each such pair -- the twins are counted once
+        plain = {a for _, a in stores if not a.endswith(" nt")}
+        twins = sum(1 for _, a in stores if a.endswith(" nt") and a[:-3] in plain)
+        executed = len(stores) - twins
         checked += 1
-        if loads != kpt // 4 or len(stores) != kpt + 1 or wide:
-            bad.append((name, "trip loop has %d LDS-DMA loads (want %d) and %d stores (want %d)%s"
-                        % (loads, kpt // 4, len(stores), kpt + 1, ", not all single dwords: %s" % wide if wide else "")))
+        if loads != kpt // 4 or executed != kpt + 1 or wide:
+            bad.append((name, "trip loop has %d LDS-DMA loads (want %d) and executes %d stores per trip (%d in the code, %d "
+                              "non-temporal twins; want %d)%s"
+                        % (loads, kpt // 4, executed, len(stores), twins, kpt + 1,
+                           ", not all single dwords: %s" % wide if wide else "")))
     if not checked:
         raise SystemExit("check_fused_stores: no fused beta_grads_lds_kernel instantiation found in %s" % obj)
     if bad:
